@@ -1,0 +1,87 @@
+/*
+ * mzs_layout.h — packed weight-blob layout and node numbering shared by the
+ * C-ABI library (muzero_amd/csrc) and the CPU oracle (oracle/).
+ *
+ * Weight blob: fp32, every matrix row-major [out][in] exactly as torch stores
+ * nn.Linear.weight, every vector [out].  Order (L = n_mid_layers; the mid layer
+ * is ONE tied tensor per net, applied L times — the reference repeats the same
+ * linear_mid object, neural_network_mlp_model.py:33-39, :75-84, :116-122):
+ *
+ *   representation (neural_network_mlp_model.py:7-44)
+ *     r_in_w [H][obs]   r_in_b [H]   (r_mid_w [H][H]  r_mid_b [H] if L>0)
+ *     r_out_w [Sd][H]   r_out_b [Sd]
+ *   dynamics (neural_network_mlp_model.py:49-88; trunk shared by both heads)
+ *     d_in_w [H][Sd+A]  d_in_b [H]   (d_mid_w [H][H]  d_mid_b [H] if L>0)
+ *     d_rew_w [Sd][H]   d_rew_b [Sd]   d_st_w [Sd][H]   d_st_b [Sd]
+ *   prediction (neural_network_mlp_model.py:92-128; trunk shared by both heads)
+ *     p_in_w [H][Sd]    p_in_b [H]   (p_mid_w [H][H]  p_mid_b [H] if L>0)
+ *     p_pol_w [A][H]    p_pol_b [A]    p_val_w [Sd][H]  p_val_b [Sd]
+ *
+ * Node numbering of one game's tree (replaces the Node objects of
+ * monte_carlo_tree_search.py:6-20): node 0 is the root; the A children created
+ * by the e-th expansion live at 1 + e*A + a.  Expansion 0 is the root expansion
+ * (monte_carlo_tree_search.py:113-123), expansion s+1 belongs to simulation s
+ * (:195-200).  Nodes per game: 1 + A*(S+1).
+ */
+#ifndef MZS_LAYOUT_H
+#define MZS_LAYOUT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+typedef struct mzs_dims {
+    int32_t obs_dim;      /* flattened observation length                    */
+    int32_t n_actions;    /* A                                               */
+    int32_t state_dim;    /* S_dim: hidden-state width == support size       */
+    int32_t hidden_dim;   /* H                                               */
+    int32_t n_mid_layers; /* L: how many times the tied mid layer is applied */
+} mzs_dims;
+
+typedef struct mzs_blob_offsets {
+    size_t r_in_w, r_in_b, r_mid_w, r_mid_b, r_out_w, r_out_b;
+    size_t d_in_w, d_in_b, d_mid_w, d_mid_b, d_rew_w, d_rew_b, d_st_w, d_st_b;
+    size_t p_in_w, p_in_b, p_mid_w, p_mid_b, p_pol_w, p_pol_b, p_val_w, p_val_b;
+    size_t total;
+} mzs_blob_offsets;
+
+static inline mzs_blob_offsets mzs_blob_layout(const mzs_dims* d) {
+    mzs_blob_offsets o;
+    size_t H = (size_t)d->hidden_dim, Sd = (size_t)d->state_dim, A = (size_t)d->n_actions;
+    size_t ob = (size_t)d->obs_dim, mid = d->n_mid_layers > 0 ? 1 : 0, p = 0;
+    o.r_in_w = p;  p += H * ob;
+    o.r_in_b = p;  p += H;
+    o.r_mid_w = p; p += mid * H * H;
+    o.r_mid_b = p; p += mid * H;
+    o.r_out_w = p; p += Sd * H;
+    o.r_out_b = p; p += Sd;
+    o.d_in_w = p;  p += H * (Sd + A);
+    o.d_in_b = p;  p += H;
+    o.d_mid_w = p; p += mid * H * H;
+    o.d_mid_b = p; p += mid * H;
+    o.d_rew_w = p; p += Sd * H;
+    o.d_rew_b = p; p += Sd;
+    o.d_st_w = p;  p += Sd * H;
+    o.d_st_b = p;  p += Sd;
+    o.p_in_w = p;  p += H * Sd;
+    o.p_in_b = p;  p += H;
+    o.p_mid_w = p; p += mid * H * H;
+    o.p_mid_b = p; p += mid * H;
+    o.p_pol_w = p; p += A * H;
+    o.p_pol_b = p; p += A;
+    o.p_val_w = p; p += Sd * H;
+    o.p_val_b = p; p += Sd;
+    o.total = p;
+    return o;
+}
+
+static inline int32_t mzs_nodes_per_game(int32_t n_actions, int32_t num_simulations) {
+    return 1 + n_actions * (num_simulations + 1);
+}
+
+/* Upper bound on tie-break draws one search can consume: A per level, and the
+ * descent of simulation s visits at most s+1 levels (monte_carlo_tree_search.py:163,172). */
+static inline int64_t mzs_max_draws(int32_t n_actions, int32_t num_simulations) {
+    return (int64_t)n_actions * num_simulations * (num_simulations + 1) / 2;
+}
+
+#endif /* MZS_LAYOUT_H */

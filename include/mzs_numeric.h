@@ -1,0 +1,127 @@
+/*
+ * mzs_numeric.h — the fp32/fp64 arithmetic contract of the MuZero search path.
+ *
+ * The reference (DHDev0/Muzero) evaluates its MLPs with torch-CPU kernels whose
+ * summation order and libm are not reproducible on a GPU.  This header pins ONE
+ * evaluation order for every floating-point step of the model half of the path,
+ * so that the HIP kernels (muzero_amd/csrc) and the CPU oracle (oracle/) produce
+ * bit-identical numbers, and both stay within 1e-5 relative of the reference
+ * (checked against tests/golden/model_L2_*.npz).
+ *
+ * Contract (every operation is an individually rounded IEEE-754 binary32 op;
+ * compile with -ffp-contract=off on both sides):
+ *   dot      : acc = bias; for k ascending: acc = fma(w[k], x[k], acc)
+ *              (== what v_mfma_f32_*_f32 computes: a k-ordered fmaf chain)
+ *   sum      : pairwise halving tree over the array zero-padded to a power of two
+ *              (off = P/2 … 1: v[i] += v[i+off]) == a wave shuffle-down reduction
+ *   exp      : mzs_expf below (Cody-Waite reduction + degree-6 Cephes polynomial)
+ *   expm1    : mzs_expm1f_neg below, x <= 0 only (ELU negative branch)
+ *   sqrt, /  : correctly rounded (hipcc: -fhip-fp32-correctly-rounded-divide-sqrt)
+ *
+ * Reference formulas restated here:
+ *   ELU                            torch.nn.ELU, neural_network_mlp_model.py:26,68,109
+ *   scale_to_bound_action          neural_network_mlp_model.py:135-143
+ *   inverse_transform_with_support muzero_model.py:571-587
+ *   softmax(policy)                muzero_model.py:898
+ */
+#ifndef MZS_NUMERIC_H
+#define MZS_NUMERIC_H
+
+#if defined(__HIPCC__)
+#define MZS_FN __host__ __device__ __forceinline__
+#else
+#define MZS_FN static inline
+#endif
+
+MZS_FN float mzs_fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+
+MZS_FN float mzs_bits2f(int i) {
+    float f;
+    __builtin_memcpy(&f, &i, 4);
+    return f;
+}
+
+MZS_FN int mzs_f2bits(float f) {
+    int i;
+    __builtin_memcpy(&i, &f, 4);
+    return i;
+}
+
+/* 2^n for integer n in [-126, 127], exact. */
+MZS_FN float mzs_pow2i(int n) { return mzs_bits2f((n + 127) << 23); }
+
+/* e^r - 1 for |r| <= ln2/2 (+ a little): r + r^2 * P(r), Cephes expf coefficients. */
+MZS_FN float mzs_expm1_poly(float r) {
+    float p = 1.9875691500e-4f;
+    p = mzs_fma(p, r, 1.3981999507e-3f);
+    p = mzs_fma(p, r, 8.3334519073e-3f);
+    p = mzs_fma(p, r, 4.1665795894e-2f);
+    p = mzs_fma(p, r, 1.6666665459e-1f);
+    p = mzs_fma(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    return mzs_fma(p, r2, r);
+}
+
+/* Cody-Waite split of x = n*ln2 + r. */
+MZS_FN float mzs_exp_reduce(float x, int* n_out) {
+    float t = x * 1.44269504088896341f;
+    float n = __builtin_rintf(t);
+    float r = mzs_fma(n, -0.693359375f, x);          /* ln2 high part (exact in 10 bits) */
+    r = mzs_fma(n, 2.12194440e-4f, r);               /* minus ln2 low part               */
+    *n_out = (int)n;
+    return r;
+}
+
+/* exp(x); results below FLT_MIN flush to 0, inputs above 88 saturate. */
+MZS_FN float mzs_expf(float x) {
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    int n;
+    float r = mzs_exp_reduce(x, &n);
+    float e = mzs_expm1_poly(r) + 1.0f;
+    return e * mzs_pow2i(n);
+}
+
+/* expm1(x) for x <= 0: 2^n * (e^r - 1) + (2^n - 1), one fma at the end. */
+MZS_FN float mzs_expm1f_neg(float x) {
+    if (x < -87.0f) return -1.0f;
+    int n;
+    float r = mzs_exp_reduce(x, &n);
+    float p = mzs_expm1_poly(r);
+    float s = mzs_pow2i(n);
+    return mzs_fma(s, p, s - 1.0f);
+}
+
+/* torch.nn.ELU(alpha=1) */
+MZS_FN float mzs_elu(float x) { return x > 0.0f ? x : mzs_expm1f_neg(x); }
+
+/* Scalar tail of inverse_transform_with_support (muzero_model.py:585-586). */
+MZS_FN float mzs_inverse_value_transform(float y) {
+    float a = __builtin_fabsf(y);
+    float t = (a + 1.0f) + 0.001f;
+    t = 0.004f * t;
+    t = 1.0f + t;
+    float r = __builtin_sqrtf(t);
+    r = r - 1.0f;
+    r = r / 0.002f;
+    r = r * r;
+    r = r - 1.0f;
+    float sg = (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f);
+    return sg * r;
+}
+
+/* scale_to_bound_action denominator (neural_network_mlp_model.py:138-139). */
+MZS_FN float mzs_bound_scale(float mn, float mx) {
+    float sc = mx - mn;
+    if (sc < 1e-5f) sc = sc + 1e-5f;
+    return sc;
+}
+
+/* next power of two >= n (n >= 1) */
+MZS_FN int mzs_pow2_ceil(int n) {
+    int p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+#endif /* MZS_NUMERIC_H */

@@ -1,0 +1,90 @@
+/*
+ * mz_oracle.h — CPU oracle for the MuZero self-play search path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in muzero_amd/ may include, link or call
+ * this; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do.
+ *
+ * It restates, in plain C, the algorithm of the reference
+ * (/root/reference, DHDev0/Muzero):
+ *   search : monte_carlo_tree_search.py:113-265
+ *   model  : neural_network_mlp_model.py:7-143, muzero_model.py:490-517,:571-587,
+ *            :828-905
+ * under the arithmetic contract of include/mzs_numeric.h.
+ *
+ * Pinning (tests/test_oracle_golden.py, fixtures made by
+ * tests/golden/make_fixtures.py importing the reference in the build container):
+ *   L1  search with the reference's own model outputs injected: visit counts,
+ *       expanded leaves, root value, draws consumed — bit-exact on every fixture;
+ *   L2  model functions within 1e-5 relative of the reference wrappers;
+ *   L3  end-to-end search: bit-exact visit counts on every fixture search whose
+ *       recorded minimum decision margin is >= 1e-4 (near-ties below the model
+ *       tolerance may legitimately flip), root values within 1e-5 relative.
+ */
+#ifndef MZ_ORACLE_H
+#define MZ_ORACLE_H
+
+#include "../include/mzs_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mzo_search_cfg {
+    mzs_dims dims;
+    int32_t num_simulations;      /* S                                            */
+    int32_t train;                /* add Dirichlet noise at the root (mcts.py:134) */
+    int32_t n_threads;            /* games are sharded over OpenMP threads         */
+    int32_t _pad;
+    double discount;              /* gamma, rounded to fp32 where the reference does */
+    double exploration_fraction;  /* root_exploration_fraction                     */
+    const double* pbc_table;      /* [S+1]: sqrt(n)*(log((n+base+1)/base)+init), host numpy */
+} mzo_search_cfg;
+
+/* L1 mode: model outputs supplied per simulation instead of computed. */
+typedef struct mzo_table_model {
+    const float* root_policy; /* [G][A]    softmax prior of the root               */
+    const float* sim_reward;  /* [G][S]    reward of the leaf expanded at sim s    */
+    const float* sim_value;   /* [G][S]    value  of that leaf                     */
+    const float* sim_prior;   /* [G][S][A] prior of its children                   */
+} mzo_table_model;
+
+/* Any pointer may be NULL. N = 1 + A*(S+1). */
+typedef struct mzo_search_out {
+    int32_t* visits;      /* [G][A] root-child visit counts (mcts.py:219)         */
+    float* root_value;    /* [G]    root.value() (mcts.py:19-20)                  */
+    double* root_prior;   /* [G][A] root-child priors after noise (mcts.py:144)   */
+    int64_t* consumed;    /* [G]    tie-break draws consumed (mcts.py:163)        */
+    int64_t* path_len;    /* [G]    sum over sims of selections made (mcts.py:173-176) */
+    int32_t* sim_leaf;    /* [G][S] node expanded by simulation s                 */
+    int32_t* node_visit;  /* [G][N] */
+    float* node_vsum;     /* [G][N] */
+    float* node_reward;   /* [G][N] */
+    float* node_prior;    /* [G][N] */
+    int32_t* child_base;  /* [G][N] first child index, 0 = not expanded           */
+    float* minmax;        /* [G][2] MinMaxStats minimum, maximum (mcts.py:23-35)  */
+    double* min_margin;   /* [G]    smallest gap between best and runner-up score */
+    float* hidden;        /* [G][S+1][S_dim] hidden state of each expansion       */
+} mzo_search_out;
+
+void mzo_representation(const mzs_dims* d, const float* blob, const float* obs, int32_t B,
+                        float* hidden);
+void mzo_dynamics(const mzs_dims* d, const float* blob, const float* hidden,
+                  const int32_t* action, int32_t B, float* reward, float* next_hidden);
+void mzo_prediction(const mzs_dims* d, const float* blob, const float* hidden, int32_t B,
+                    float* policy, float* value);
+
+/* building blocks exposed for unit pinning */
+void mzo_scale_to_bound(const float* x, int32_t n, float* y);
+float mzo_support_to_scalar(const float* logits, int32_t n);
+float mzo_expf(float x);
+float mzo_elu(float x);
+
+/* returns 0, or -1 on a bad argument */
+int mzo_search(const mzo_search_cfg* cfg, const float* blob, const mzo_table_model* tbl,
+               const float* obs, const double* dirichlet, const double* noise,
+               int64_t noise_stride, int32_t G, const mzo_search_out* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

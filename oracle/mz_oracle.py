@@ -1,0 +1,170 @@
+"""ctypes front end of the CPU oracle (oracle/libmzoracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py; never by muzero_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class Dims(C.Structure):
+    _fields_ = [("obs_dim", C.c_int32), ("n_actions", C.c_int32), ("state_dim", C.c_int32),
+                ("hidden_dim", C.c_int32), ("n_mid_layers", C.c_int32)]
+
+
+class SearchCfg(C.Structure):
+    _fields_ = [("dims", Dims), ("num_simulations", C.c_int32), ("train", C.c_int32),
+                ("n_threads", C.c_int32), ("_pad", C.c_int32), ("discount", C.c_double),
+                ("exploration_fraction", C.c_double), ("pbc_table", C.c_void_p)]
+
+
+class TableModel(C.Structure):
+    _fields_ = [("root_policy", C.c_void_p), ("sim_reward", C.c_void_p),
+                ("sim_value", C.c_void_p), ("sim_prior", C.c_void_p)]
+
+
+_OUT_FIELDS = ["visits", "root_value", "root_prior", "consumed", "path_len", "sim_leaf",
+               "node_visit", "node_vsum", "node_reward", "node_prior", "child_base", "minmax",
+               "min_margin", "hidden"]
+
+
+class SearchOut(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _OUT_FIELDS]
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "libmzoracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "libmzoracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.mzo_search.restype = C.c_int
+        _LIB.mzo_support_to_scalar.restype = C.c_float
+        _LIB.mzo_support_to_scalar.argtypes = [C.c_void_p, C.c_int32]
+        _LIB.mzo_expf.restype = C.c_float
+        _LIB.mzo_expf.argtypes = [C.c_float]
+        _LIB.mzo_elu.restype = C.c_float
+        _LIB.mzo_elu.argtypes = [C.c_float]
+    return _LIB
+
+
+def dims(obs_dim, A, S_dim, H, L):
+    return Dims(int(obs_dim), int(A), int(S_dim), int(H), int(L))
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def representation(d, blob, obs):
+    obs = _f32(obs)
+    B = obs.shape[0]
+    hid = np.empty((B, d.state_dim), np.float32)
+    lib().mzo_representation(C.byref(d), _p(_f32(blob)), _p(obs), C.c_int32(B), _p(hid))
+    return hid
+
+
+def dynamics(d, blob, hidden, action):
+    hidden = _f32(hidden)
+    action = np.ascontiguousarray(action, dtype=np.int32)
+    B = hidden.shape[0]
+    rew = np.empty(B, np.float32)
+    nh = np.empty((B, d.state_dim), np.float32)
+    lib().mzo_dynamics(C.byref(d), _p(_f32(blob)), _p(hidden), _p(action), C.c_int32(B), _p(rew), _p(nh))
+    return rew, nh
+
+
+def prediction(d, blob, hidden):
+    hidden = _f32(hidden)
+    B = hidden.shape[0]
+    pol = np.empty((B, d.n_actions), np.float32)
+    val = np.empty(B, np.float32)
+    lib().mzo_prediction(C.byref(d), _p(_f32(blob)), _p(hidden), C.c_int32(B), _p(pol), _p(val))
+    return pol, val
+
+
+def initial_inference(d, blob, obs):
+    h = representation(d, blob, obs)
+    p, v = prediction(d, blob, h)
+    return h, p, v
+
+
+def recurrent_inference(d, blob, hidden, action):
+    r, nh = dynamics(d, blob, hidden, action)
+    p, v = prediction(d, blob, nh)
+    return r, nh, p, v
+
+
+def scale_to_bound(x):
+    x = _f32(x)
+    y = np.empty_like(x)
+    for i in range(x.shape[0]):
+        lib().mzo_scale_to_bound(_p(x[i]), C.c_int32(x.shape[1]), _p(y[i]))
+    return y
+
+
+def support_to_scalar(logits):
+    logits = _f32(logits)
+    return np.array([lib().mzo_support_to_scalar(_p(logits[i]), logits.shape[1])
+                     for i in range(logits.shape[0])], np.float32)
+
+
+def search(d, blob, S, gamma, frac, pbc_table, obs=None, dirichlet=None, noise=None, train=True,
+           table=None, n_threads=1, want=("visits", "root_value", "root_prior", "consumed",
+                                          "path_len", "sim_leaf", "min_margin")):
+    """Run G searches. ``noise`` is [G, stride] float64 tie-break draws, ``dirichlet``
+    [G, A] float64. ``table`` = dict(root_policy, sim_reward, sim_value, sim_prior)
+    switches to the injected-model (L1) mode. Returns a dict of numpy arrays."""
+    A = d.n_actions
+    if table is not None:
+        G = np.asarray(table["root_policy"]).shape[0]
+    else:
+        obs = _f32(obs)
+        G = obs.shape[0]
+    N = 1 + A * (S + 1)
+    pbc = np.ascontiguousarray(pbc_table, dtype=np.float64)
+    assert pbc.shape[0] >= max(S, 1)
+    if noise is not None:
+        noise = np.ascontiguousarray(noise, dtype=np.float64)
+        assert noise.ndim == 2 and noise.shape[0] == G
+    if dirichlet is not None:
+        dirichlet = np.ascontiguousarray(dirichlet, dtype=np.float64)
+    cfg = SearchCfg(d, int(S), int(bool(train)), int(n_threads), 0, float(gamma), float(frac),
+                    _p(pbc).value)
+    shapes = dict(visits=((G, A), np.int32), root_value=((G,), np.float32),
+                  root_prior=((G, A), np.float64), consumed=((G,), np.int64),
+                  path_len=((G,), np.int64), sim_leaf=((G, S), np.int32),
+                  node_visit=((G, N), np.int32), node_vsum=((G, N), np.float32),
+                  node_reward=((G, N), np.float32), node_prior=((G, N), np.float32),
+                  child_base=((G, N), np.int32), minmax=((G, 2), np.float32),
+                  min_margin=((G,), np.float64), hidden=((G, S + 1, d.state_dim), np.float32))
+    res = {k: np.zeros(*shapes[k]) for k in want}
+    out = SearchOut(*[(_p(res[k]).value if k in res else None) for k in _OUT_FIELDS])
+    tbl = None
+    keep = []
+    if table is not None:
+        keep = [_f32(table[k]) for k in ("root_policy", "sim_reward", "sim_value", "sim_prior")]
+        tbl = TableModel(*[_p(a).value for a in keep])
+    blob_c = None if blob is None else _f32(blob)
+    rc = lib().mzo_search(C.byref(cfg), _p(blob_c), C.byref(tbl) if tbl is not None else None,
+                          _p(obs), _p(dirichlet), _p(noise),
+                          C.c_int64(noise.shape[1] if noise is not None else 0), C.c_int32(G),
+                          C.byref(out))
+    if rc != 0:
+        raise RuntimeError(f"mzo_search failed: {rc}")
+    return res
