@@ -12,8 +12,9 @@
  * compile with -ffp-contract=off on both sides):
  *   dot      : acc = bias; for k ascending: acc = fma(w[k], x[k], acc)
  *              (== what v_mfma_f32_*_f32 computes: a k-ordered fmaf chain)
- *   sum      : pairwise halving tree over the array zero-padded to a power of two
- *              (off = P/2 … 1: v[i] += v[i+off]) == a wave shuffle-down reduction
+ *   sum      : adjacent-pair tree over the array zero-padded to a power of two
+ *              (v[i] = v[2i] + v[2i+1], repeated) == lane-local pair sum followed by a
+ *              wave xor-butterfly (a + b == b + a bitwise)
  *   exp      : mzs_expf below (Cody-Waite reduction + degree-6 Cephes polynomial)
  *   expm1    : mzs_expm1f_neg below, x <= 0 only (ELU negative branch)
  *   sqrt, /  : correctly rounded (hipcc: -fhip-fp32-correctly-rounded-divide-sqrt)

@@ -1,0 +1,138 @@
+/*
+ * mzsearch.h — C-ABI of libmzsearch.so, the MI355X (gfx950) implementation of the
+ * MuZero self-play search hot path of DHDev0/Muzero.
+ *
+ * The reference has no FFI for this path: the seam is three Python call surfaces
+ * (SURVEY.md §8b).  Each entry point below names the reference code it replaces;
+ * muzero_amd/search.py and muzero_amd/model.py bind them with ctypes and present
+ * the reference's own classes on top.
+ *
+ * Conventions: every function returns 0 on success or a negative MZS_E_* code and
+ * never throws; mzs_last_error() describes the last failure on the calling thread.
+ * "_dev" pointers are device memory on the handle's GPU, owned by the caller and
+ * borrowed for the duration of the call.  `stream` is a hipStream_t (pass
+ * torch.cuda.current_stream().cuda_stream); calls only enqueue work, the caller
+ * synchronises.  One handle per (GPU, stream); a handle is not thread-safe.
+ * Arithmetic follows include/mzs_numeric.h; weight blob and node numbering follow
+ * include/mzs_layout.h.
+ */
+#ifndef MZSEARCH_H
+#define MZSEARCH_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "mzs_layout.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MZS_OK 0
+#define MZS_E_ARG (-1)      /* bad argument / unsupported size */
+#define MZS_E_HIP (-2)      /* a HIP runtime call failed       */
+#define MZS_E_STATE (-3)    /* call out of order (e.g. search before set_weights) */
+
+/* search engines */
+#define MZS_ENGINE_FUSED 0    /* one persistent launch: wave per game, tree in LDS */
+#define MZS_ENGINE_LOCKSTEP 1 /* select / inference / expand+backup kernels per simulation */
+
+typedef struct mzs_handle mzs_handle;
+
+typedef struct mzs_config {
+    mzs_dims dims;                  /* Muzero(...) ctor arguments, muzero_model.py:16-35        */
+    int32_t max_games;              /* G: concurrent games (trees) this handle can hold         */
+    int32_t max_simulations;        /* S: upper bound of num_simulations (mcts.py:224)          */
+    int32_t device;                 /* HIP device ordinal                                       */
+    int32_t engine;                 /* MZS_ENGINE_*                                             */
+    double discount;                /* Monte_carlo_tree_search.discount (mcts.py:81)            */
+    double root_exploration_fraction; /* mcts.py:83                                             */
+    const double* pbc_table;        /* host, [max_simulations+1]: sqrt(n)*(log((n+base+1)/base)+init)
+                                       for parent visit count n, evaluated by the caller in
+                                       float64 as mcts.py:156-157 does (muzero_amd.rng.pbc_table) */
+} mzs_config;
+
+/* Monte_carlo_tree_search.__init__/reset (monte_carlo_tree_search.py:38-86) + Muzero model
+ * shapes: allocates the SoA tree for max_games games and the weight store. */
+int mzs_create(const mzs_config* cfg, mzs_handle** out);
+void mzs_destroy(mzs_handle* h);
+
+/* Number of floats mzs_set_weights expects (include/mzs_layout.h). */
+size_t mzs_weight_count(const mzs_dims* dims);
+
+/* Replaces holding the three nn.Modules (muzero_model.py:257-273): uploads the packed fp32
+ * weights.  `blob` may be a host or a device pointer. */
+int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats);
+
+/* Monte_carlo_tree_search.run (monte_carlo_tree_search.py:224-265) for n_games games at once.
+ *   obs_dev       [n_games][obs_dim] f32   observation of each game's root
+ *   dirichlet_dev [n_games][A] f64         np.random.dirichlet([alpha]*A) per game (mcts.py:140);
+ *                                          may be NULL when train == 0 or num_simulations == 0
+ *   noise_dev     [n_games][noise_stride] f64  the np.random.uniform(1e-7, 2e-7) tie-break draws
+ *                                          in consumption order (mcts.py:163); stride >=
+ *                                          mzs_max_draws(A, num_simulations)
+ * Results stay in the handle (mzs_results / mzs_tree_array). */
+int mzs_search(mzs_handle* h, int32_t n_games, int32_t num_simulations, int32_t train,
+               const float* obs_dev, const double* dirichlet_dev, const double* noise_dev,
+               int64_t noise_stride, void* stream);
+
+/* Same search with the model outputs supplied instead of computed (L1 parity mode): isolates
+ * ucb_score/select_child/expand/backup (mcts.py:155-209) from the network arithmetic.
+ *   root_policy_dev [n_games][A], sim_reward_dev/sim_value_dev [n_games][S],
+ *   sim_prior_dev [n_games][S][A]: what prediction/dynamics returned at each simulation. */
+int mzs_search_injected(mzs_handle* h, int32_t n_games, int32_t num_simulations, int32_t train,
+                        const float* root_policy_dev, const float* sim_reward_dev,
+                        const float* sim_value_dev, const float* sim_prior_dev,
+                        const double* dirichlet_dev, const double* noise_dev,
+                        int64_t noise_stride, void* stream);
+
+/* generate_action_and_policy_base_on_node_count (mcts.py:215-222) + what
+ * Game.store_search_statistics reads (game.py:154-168).  Any pointer may be NULL.
+ *   visits_dev     [n_games][A] i32  root-child visit counts
+ *   root_value_dev [n_games] f32     root.value()
+ *   root_prior_dev [n_games][A] f64  root-child priors after exploration noise
+ *   consumed_dev   [n_games] i64     tie-break draws consumed (so the caller can advance its RNG)
+ *   path_len_dev   [n_games] i64     total selections made (mean path length = /S) */
+int mzs_results(mzs_handle* h, int32_t n_games, int32_t* visits_dev, float* root_value_dev,
+                double* root_prior_dev, int64_t* consumed_dev, int64_t* path_len_dev,
+                void* stream);
+
+/* Device pointers into the handle's SoA tree (row stride = mzs_tree_stride(h) elements):
+ * the arrays that replace the Node objects (mcts.py:6-20). */
+#define MZS_TREE_VISIT 0       /* i32 [G][stride]  Node.visit_count                 */
+#define MZS_TREE_VALUE_SUM 1   /* f32 [G][stride]  Node.value_sum                   */
+#define MZS_TREE_PRIOR 2       /* f32 [G][stride]  Node.prior                       */
+#define MZS_TREE_REWARD 3      /* f32 [G][stride]  Node.reward                      */
+#define MZS_TREE_CHILD_BASE 4  /* i32 [G][stride]  first child index, 0 = leaf      */
+#define MZS_TREE_SIM_LEAF 5    /* i32 [G][max_simulations] node expanded at sim s   */
+#define MZS_TREE_MINMAX 6      /* f32 [G][2]       MinMaxStats minimum, maximum     */
+#define MZS_TREE_HIDDEN 7      /* f32 [G][max_simulations+1][mzs_hidden_stride(h)]  */
+#define MZS_TREE_STATUS 8      /* i32 [G]          0 ok, 1 noise stream exhausted   */
+void* mzs_tree_array(mzs_handle* h, int32_t which);
+int32_t mzs_tree_stride(const mzs_handle* h);
+int32_t mzs_hidden_stride(const mzs_handle* h);
+
+/* Muzero.representation_function_inference + prediction_function_inference
+ * (muzero_model.py:828-845, :883-905) on a batch: hidden [B][S_dim], policy [B][A] (softmax),
+ * value [B] (after inverse_transform_with_support).  policy/value may be NULL. */
+int mzs_initial_inference(mzs_handle* h, int32_t batch, const float* obs_dev, float* hidden_dev,
+                          float* policy_dev, float* value_dev, void* stream);
+
+/* Muzero.dynamics_function_inference + prediction_function_inference on the new state
+ * (muzero_model.py:848-905): reward [B], next_hidden [B][S_dim], policy [B][A], value [B].
+ * policy/value may be NULL (dynamics only). */
+int mzs_recurrent_inference(mzs_handle* h, int32_t batch, const float* hidden_dev,
+                            const int32_t* action_dev, float* reward_dev, float* next_hidden_dev,
+                            float* policy_dev, float* value_dev, void* stream);
+
+/* Muzero.prediction_function_inference alone (muzero_model.py:883-905). */
+int mzs_prediction_inference(mzs_handle* h, int32_t batch, const float* hidden_dev,
+                             float* policy_dev, float* value_dev, void* stream);
+
+const char* mzs_last_error(void);
+const char* mzs_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MZSEARCH_H */

@@ -1,0 +1,381 @@
+/*
+ * mzs_device.h — wave-level device functions of the MuZero search path (gfx950).
+ *
+ * One 64-lane wavefront owns one game.  The game's tree lives in that wave's LDS
+ * slice as 16-byte node records; lanes 0..A-1 score one child each, lane pairs
+ * hold the (2i, 2i+1) elements of a logit vector for softmax / min-max reductions,
+ * lane j owns output neuron j of a dense layer.  No cross-wave communication.
+ *
+ * Reference code restated (file:line in /root/reference):
+ *   wave_select   monte_carlo_tree_search.py:155-177  ucb_score / select_child / descent
+ *   wave_backup   monte_carlo_tree_search.py:203-209  back_propagate_and_update_min_max_bound
+ *   wave_expand   monte_carlo_tree_search.py:186-200
+ *   model_*       neural_network_mlp_model.py:43-44, :86-88, :127-128, :135-143;
+ *                 muzero_model.py:571-587, :877-879, :898-903
+ * Arithmetic contract: include/mzs_numeric.h.
+ */
+#ifndef MZS_DEVICE_H
+#define MZS_DEVICE_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/mzs_numeric.h"
+
+namespace mzs {
+
+constexpr int kWave = 64;
+
+/* One dense layer in the device weight store: W^T as [rows][n_pad] (lane-contiguous
+ * output neurons), bias [n_pad]; padding columns are zero. */
+struct Layer {
+    int w_off;  /* float offset of W^T                               */
+    int b_off;  /* float offset of bias                              */
+    int k;      /* fan-in accumulated by the fma chain               */
+    int n_pad;  /* padded fan-out, multiple of 64                    */
+};
+
+struct Model {
+    int obs_dim, A, Sd, H, L;
+    int seg_state;  /* offset of the next-state segment in the dynamics heads (reward at 0) */
+    int seg_value;  /* offset of the value segment in the prediction heads (policy at 0)     */
+    Layer r_in, r_mid, r_out, d_in, d_mid, d_heads, p_in, p_mid, p_heads;
+    const float* w; /* device weight store */
+};
+
+/* 16-byte node record (replaces monte_carlo_tree_search.py:6-20 Node) */
+struct __attribute__((aligned(16))) Node {
+    int visit;
+    float vsum;
+    float prior;
+    float reward;
+};
+
+/* Per-wave LDS slice */
+struct WaveLds {
+    Node* nodes;          /* [n_nodes]                                         */
+    unsigned short* cb;   /* [n_nodes] first child index, 0 = leaf              */
+    unsigned short* path; /* [S+2] search_path                                  */
+    float* xh;            /* hidden state / observation (layer input)           */
+    float* xa;            /* trunk activations, ping                            */
+    float* xb;            /* trunk activations, pong                            */
+    float* ob;            /* head outputs (logit segments)                      */
+};
+
+__device__ __forceinline__ void wave_sync() {
+    /* LDS operations of one wave execute in order; this only stops the compiler
+     * from moving LDS accesses of different lanes across the phase boundary. */
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (kWave - 1); }
+
+__device__ __forceinline__ double readlane_f64(double v, int lane) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+__device__ __forceinline__ float readlane_f32(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+
+/* order-free reductions: result in every lane */
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        float t = __shfl_xor(v, o);
+        v = t > v ? t : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) {
+        float t = __shfl_xor(v, o);
+        v = t < v ? t : v;
+    }
+    return v;
+}
+
+/* contract "sum": adjacent-pair tree; lane i already holds v[2i] + v[2i+1].
+ * a + b == b + a bitwise, so the xor butterfly leaves the same total in every lane. */
+__device__ __forceinline__ float wave_tree_sum(float v) {
+#pragma unroll
+    for (int o = 1; o < kWave; o <<= 1) v = v + __shfl_xor(v, o);
+    return v;
+}
+
+/* y = act(bias + W x): lane j owns neuron j (and j+64, ...); x is broadcast from LDS.
+ * extra_row >= 0 adds that row of W^T after the chain (the one-hot action column of
+ * the dynamics input, neural_network_mlp_model.py:87 + muzero_model.py:502). */
+template <bool kElu>
+__device__ __forceinline__ void wave_dense(const float* __restrict__ w, const Layer ly,
+                                           const float* x, float* out, int extra_row, int lane) {
+    for (int j0 = 0; j0 < ly.n_pad; j0 += kWave) {
+        const int j = j0 + lane;
+        const float* __restrict__ wt = w + ly.w_off + j;
+        float acc = w[ly.b_off + j];
+        int k = 0;
+        for (; k + 4 <= ly.k; k += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(x + k);
+            const float w0 = wt[(size_t)(k + 0) * ly.n_pad];
+            const float w1 = wt[(size_t)(k + 1) * ly.n_pad];
+            const float w2 = wt[(size_t)(k + 2) * ly.n_pad];
+            const float w3 = wt[(size_t)(k + 3) * ly.n_pad];
+            acc = mzs_fma(w0, xv.x, acc);
+            acc = mzs_fma(w1, xv.y, acc);
+            acc = mzs_fma(w2, xv.z, acc);
+            acc = mzs_fma(w3, xv.w, acc);
+        }
+        for (; k < ly.k; ++k) acc = mzs_fma(wt[(size_t)k * ly.n_pad], x[k], acc);
+        if (extra_row >= 0) acc = acc + wt[(size_t)extra_row * ly.n_pad];
+        if (kElu) acc = mzs_elu(acc);
+        out[j] = acc;
+    }
+    wave_sync();
+}
+
+/* tied mid layer applied L times (neural_network_mlp_model.py:38-39); returns the
+ * buffer holding the result */
+__device__ __forceinline__ float* wave_mid_layers(const Model& m, const Layer ly, float* in,
+                                                  float* other, int lane) {
+    for (int l = 0; l < m.L; ++l) {
+        wave_dense<true>(m.w, ly, in, other, -1, lane);
+        float* t = in;
+        in = other;
+        other = t;
+    }
+    return in;
+}
+
+/* elements (2*lane, 2*lane+1) of a logit segment of length n <= 128 */
+struct Pair {
+    float a, b;
+    bool va, vb;
+};
+
+__device__ __forceinline__ Pair seg_load(const float* seg, int n, int lane) {
+    Pair p;
+    const int i = 2 * lane;
+    p.va = i < n;
+    p.vb = i + 1 < n;
+    p.a = p.va ? seg[i] : 0.0f;
+    p.b = p.vb ? seg[i + 1] : 0.0f;
+    return p;
+}
+
+/* softmax probabilities of the pair (contract exp + sum) */
+__device__ __forceinline__ Pair seg_softmax(const Pair q) {
+    const float ninf = -__builtin_inff();
+    float m = wave_max(fmaxf(q.va ? q.a : ninf, q.vb ? q.b : ninf));
+    Pair e = q;
+    e.a = q.va ? mzs_expf(q.a - m) : 0.0f;
+    e.b = q.vb ? mzs_expf(q.b - m) : 0.0f;
+    const float Z = wave_tree_sum(e.a + e.b);
+    e.a = e.a / Z;
+    e.b = e.b / Z;
+    return e;
+}
+
+/* inverse_transform_with_support (muzero_model.py:571-587) of a logit segment */
+__device__ __forceinline__ float seg_support_scalar(const float* seg, int n, int lane) {
+    const Pair p = seg_softmax(seg_load(seg, n, lane));
+    const int half = n / 2, i = 2 * lane;
+    const float ta = p.va ? (float)(i - half) * p.a : 0.0f;
+    const float tb = p.vb ? (float)(i + 1 - half) * p.b : 0.0f;
+    const float y = wave_tree_sum(ta + tb);
+    return mzs_inverse_value_transform(y);
+}
+
+/* scale_to_bound_action (neural_network_mlp_model.py:135-143): normalised row to
+ * LDS `dst` and, if not null, to global `gdst` */
+__device__ __forceinline__ void seg_scale_to_bound(const float* seg, int n, float* dst,
+                                                   float* gdst, int lane) {
+    const Pair q = seg_load(seg, n, lane);
+    const float pinf = __builtin_inff();
+    const float mn = wave_min(fminf(q.va ? q.a : pinf, q.vb ? q.b : pinf));
+    const float mx = wave_max(fmaxf(q.va ? q.a : -pinf, q.vb ? q.b : -pinf));
+    const float sc = mzs_bound_scale(mn, mx);
+    const int i = 2 * lane;
+    if (q.va) {
+        const float y = (q.a - mn) / sc;
+        dst[i] = y;
+        if (gdst) gdst[i] = y;
+    }
+    if (q.vb) {
+        const float y = (q.b - mn) / sc;
+        dst[i + 1] = y;
+        if (gdst) gdst[i + 1] = y;
+    }
+    wave_sync();
+}
+
+/* Representation_function.forward: input in L.xh[0..obs), hidden state to L.xh and gdst */
+__device__ __forceinline__ void model_representation(const Model& m, const WaveLds& L,
+                                                     float* gdst, int lane) {
+    wave_dense<true>(m.w, m.r_in, L.xh, L.xa, -1, lane);
+    float* t = wave_mid_layers(m, m.r_mid, L.xa, L.xb, lane);
+    wave_dense<false>(m.w, m.r_out, t, L.ob, -1, lane);
+    seg_scale_to_bound(L.ob, m.Sd, L.xh, gdst, lane);
+}
+
+/* Dynamics_function.forward on L.xh + action: reward returned (uniform), next hidden
+ * state to L.xh and gdst */
+__device__ __forceinline__ float model_dynamics(const Model& m, const WaveLds& L, int action,
+                                                float* gdst, int lane) {
+    wave_dense<true>(m.w, m.d_in, L.xh, L.xa, m.Sd + action, lane);
+    float* t = wave_mid_layers(m, m.d_mid, L.xa, L.xb, lane);
+    wave_dense<false>(m.w, m.d_heads, t, L.ob, -1, lane);
+    const float reward = seg_support_scalar(L.ob, m.Sd, lane);
+    seg_scale_to_bound(L.ob + m.seg_state, m.Sd, L.xh, gdst, lane);
+    return reward;
+}
+
+/* Prediction_function.forward on L.xh: softmax policy as lane pairs, value (uniform) */
+__device__ __forceinline__ float model_prediction(const Model& m, const WaveLds& L, Pair* policy,
+                                                  int lane) {
+    wave_dense<true>(m.w, m.p_in, L.xh, L.xa, -1, lane);
+    float* t = wave_mid_layers(m, m.p_mid, L.xa, L.xb, lane);
+    wave_dense<false>(m.w, m.p_heads, t, L.ob, -1, lane);
+    *policy = seg_softmax(seg_load(L.ob, m.A, lane));
+    return seg_support_scalar(L.ob + m.seg_value, m.Sd, lane);
+}
+
+/* ------------------------------------------------------------------ search */
+
+struct SearchConst {
+    int A, S, n_nodes;
+    float g32;            /* discount rounded to fp32 (python float * np.float32)    */
+    const double* pbc;    /* device [S+2] sqrt(n)*pb_c(n)                             */
+    const double* noise;  /* this game's tie-break draws                             */
+    long long noise_cap;  /* draws available                                         */
+};
+
+struct SearchState {
+    float mn, mx;          /* MinMaxStats                                            */
+    double root_prior;     /* lane a: prior of root child a after noise (f64)        */
+    long long consumed;    /* tie-break draws consumed                               */
+    long long win_base;    /* first draw held in the register window                 */
+    double win;            /* lane l holds draw win_base + l                         */
+    long long path_total;
+    int status;
+};
+
+__device__ __forceinline__ void noise_refill(const SearchConst& c, SearchState& s, int lane) {
+    s.win_base = s.consumed;
+    const long long i = s.win_base + lane;
+    s.win = i < c.noise_cap ? c.noise[i] : 0.0;
+}
+
+/* Descent from the root to an unexpanded node. Returns the leaf; *depth = number of
+ * selections, *action = last action, *parent_base = child_base of the leaf's parent. */
+__device__ __forceinline__ int wave_select(const SearchConst& c, SearchState& s, const WaveLds& L,
+                                           int* depth, int* action, int* parent_base, int lane) {
+    int node = 0, d = 0, act = 0, base = 0;
+    int cbn = __builtin_amdgcn_readfirstlane((int)L.cb[0]);
+    if (lane == 0) L.path[0] = 0;
+    while (cbn != 0) {
+        base = cbn;
+        const int np = __builtin_amdgcn_readfirstlane(L.nodes[node].visit);
+        const double tn = c.pbc[np];
+        if (s.consumed + c.A > s.win_base + kWave) noise_refill(c, s, lane);
+        if (s.consumed + c.A > c.noise_cap) s.status = 1;
+        const int src = (int)(s.consumed - s.win_base) + lane;
+        const double u = __shfl(s.win, src & (kWave - 1));
+        double score = 0.0;
+        int mycb = 0;
+        if (lane < c.A) {
+            /* ucb_score (mcts.py:155-163) */
+            const Node ch = L.nodes[base + lane];
+            mycb = L.cb[base + lane];
+            const double pd = node == 0 ? s.root_prior : (double)ch.prior;
+            const double ps = (tn * pd) / (double)(ch.visit + 1);
+            double vs = 0.0;
+            if (ch.visit > 0) {
+                const float q = ch.vsum / (float)ch.visit;
+                float x = c.g32 * q;
+                x = ch.reward + x;
+                if (s.mx > s.mn) x = (x - s.mn) / (s.mx - s.mn);
+                vs = (double)x;
+            }
+            score = (ps + vs) + u;
+        }
+        /* max over (score, action) tuples: ties -> larger action (mcts.py:167) */
+        double best = readlane_f64(score, 0);
+        int besta = 0;
+        for (int a = 1; a < c.A; ++a) {
+            const double sc = readlane_f64(score, a);
+            if (sc >= best) {
+                best = sc;
+                besta = a;
+            }
+        }
+        s.consumed += c.A;
+        act = besta;
+        node = base + besta;
+        cbn = __builtin_amdgcn_readlane(mycb, besta);
+        ++d;
+        if (lane == 0) L.path[d] = (unsigned short)node;
+    }
+    s.path_total += d;
+    *depth = d;
+    *action = act;
+    *parent_base = base;
+    wave_sync();
+    return node;
+}
+
+/* update_reward... + create_new_node... (mcts.py:186-200): children of expansion e */
+__device__ __forceinline__ void wave_expand(const SearchConst& c, const WaveLds& L, int leaf,
+                                            int e, float reward, const Pair pol, int lane) {
+    const int cbase = 1 + e * c.A;
+    const int i = 2 * lane;
+    if (pol.va) L.nodes[cbase + i].prior = pol.a;
+    if (pol.vb) L.nodes[cbase + i + 1].prior = pol.b;
+    if (lane == 0) {
+        L.nodes[leaf].reward = reward;
+        L.cb[leaf] = (unsigned short)cbase;
+    }
+    wave_sync();
+}
+
+/* back_propagate_and_update_min_max_bound (mcts.py:203-209): path[0..depth], leaf last.
+ * The value recurrence is a serial fp32 chain (product and sum rounded separately);
+ * the per-node updates and the min/max of the new means are done one node per lane. */
+__device__ __forceinline__ void wave_backup(const SearchConst& c, SearchState& s, const WaveLds& L,
+                                            int depth, float value, int lane) {
+    float v = value;
+    for (int top = depth; top >= 0; top -= kWave) {
+        const int cnt = top + 1 < kWave ? top + 1 : kWave;
+        const bool valid = lane < cnt;
+        const int node = valid ? L.path[top - lane] : 0;
+        Node nd = L.nodes[node];
+        float myv = 0.0f;
+        for (int k = 0; k < cnt; ++k) {
+            const float r = readlane_f32(nd.reward, k);
+            myv = lane == k ? v : myv;
+            const float gv = c.g32 * v;
+            v = r + gv;
+        }
+        const float pinf = __builtin_inff();
+        float q = 0.0f;
+        if (valid) {
+            nd.vsum = nd.vsum + myv;
+            nd.visit += 1;
+            q = nd.vsum / (float)nd.visit;
+            L.nodes[node].vsum = nd.vsum;
+            L.nodes[node].visit = nd.visit;
+        }
+        const float qmx = wave_max(valid ? q : -pinf);
+        const float qmn = wave_min(valid ? q : pinf);
+        s.mx = qmx > s.mx ? qmx : s.mx;
+        s.mn = qmn < s.mn ? qmn : s.mn;
+    }
+    wave_sync();
+}
+
+}  // namespace mzs
+#endif

@@ -1,0 +1,677 @@
+/*
+ * mzsearch.hip — kernels and C-ABI of libmzsearch.so (gfx950 only).
+ * Entry points and the reference code each replaces: include/mzsearch.h.
+ *
+ * Build: muzero_amd/csrc/Makefile
+ *   hipcc --offload-arch=gfx950 -O3 -ffp-contract=off
+ *         -fhip-fp32-correctly-rounded-divide-sqrt -shared -fPIC
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/mzsearch.h"
+#include "mzs_device.h"
+
+using namespace mzs;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess)                                                              \
+            return fail(MZS_E_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));     \
+    } while (0)
+
+inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+/* byte offsets inside one wave's LDS slice */
+struct LdsLayout {
+    int off_cb, off_path, off_xh, off_xa, off_xb, off_ob, bytes;
+};
+
+struct TreeArrays {
+    int* visit;
+    float* vsum;
+    float* prior;
+    float* reward;
+    int* child_base;
+    int* sim_leaf;
+    float* minmax;
+    float* hidden;
+    int* status;
+    int stride;      /* elements per game in the node arrays */
+    int hid_stride;  /* floats per hidden state              */
+    int max_sims;
+};
+
+struct Results {
+    int* visits;
+    float* root_value;
+    double* root_prior;
+    long long* consumed;
+    long long* path_len;
+};
+
+struct SearchParams {
+    Model m;
+    LdsLayout lds;
+    TreeArrays t;
+    Results r;
+    int n_games, S, train, n_nodes;
+    float g32, omf32;
+    double frac;
+    const double* pbc;
+    const float* obs;
+    const double* dirichlet;
+    const double* noise;
+    long long noise_stride;
+    const float* t_root_policy;
+    const float* t_reward;
+    const float* t_value;
+    const float* t_prior;
+};
+
+__device__ __forceinline__ WaveLds carve(unsigned char* base, const LdsLayout& l) {
+    WaveLds L;
+    L.nodes = reinterpret_cast<Node*>(base);
+    L.cb = reinterpret_cast<unsigned short*>(base + l.off_cb);
+    L.path = reinterpret_cast<unsigned short*>(base + l.off_path);
+    L.xh = reinterpret_cast<float*>(base + l.off_xh);
+    L.xa = reinterpret_cast<float*>(base + l.off_xa);
+    L.xb = reinterpret_cast<float*>(base + l.off_xb);
+    L.ob = reinterpret_cast<float*>(base + l.off_ob);
+    return L;
+}
+
+/* lane pair (2i, 2i+1) of a global row of length n */
+__device__ __forceinline__ Pair pair_from_global(const float* row, int n, int lane) {
+    Pair p;
+    const int i = 2 * lane;
+    p.va = i < n;
+    p.vb = i + 1 < n;
+    p.a = p.va ? row[i] : 0.0f;
+    p.b = p.vb ? row[i + 1] : 0.0f;
+    return p;
+}
+
+__device__ __forceinline__ void pair_to_global(float* row, const Pair p, int lane) {
+    const int i = 2 * lane;
+    if (p.va) row[i] = p.a;
+    if (p.vb) row[i + 1] = p.b;
+}
+
+/* ------------------------------------------------------------------------------
+ * Fused engine: Monte_carlo_tree_search.run (monte_carlo_tree_search.py:224-265) for
+ * one game per wavefront, all simulations in one launch, tree resident in LDS and
+ * written to the HBM structure-of-arrays once at the end.
+ * ---------------------------------------------------------------------------- */
+template <bool kInjected>
+__global__ void __launch_bounds__(256) k_search_fused(const SearchParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int g = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (g >= p.n_games) return; /* no block-level barrier anywhere below */
+    const WaveLds L = carve(smem + (size_t)wave * p.lds.bytes, p.lds);
+    const Model& m = p.m;
+    const int A = m.A, S = p.S;
+
+    SearchConst c;
+    c.A = A;
+    c.S = S;
+    c.n_nodes = p.n_nodes;
+    c.g32 = p.g32;
+    c.pbc = p.pbc;
+    c.noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
+    c.noise_cap = p.noise ? p.noise_stride : 0;
+
+    SearchState s;
+    s.mn = __builtin_inff();
+    s.mx = -__builtin_inff();
+    s.consumed = 0;
+    s.path_total = 0;
+    s.status = 0;
+    s.root_prior = 0.0;
+    if (c.noise) {
+        noise_refill(c, s, lane);
+    } else {
+        s.win_base = 0;
+        s.win = 0.0;
+    }
+
+    for (int n = lane; n < p.n_nodes; n += kWave) {
+        Node z;
+        z.visit = 0;
+        z.vsum = 0.0f;
+        z.prior = 0.0f;
+        z.reward = 0.0f;
+        L.nodes[n] = z;
+        L.cb[n] = 0;
+    }
+    wave_sync();
+
+    float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * p.t.hid_stride;
+
+    /* root: representation -> prediction -> expand (mcts.py:88-123) */
+    Pair pol;
+    if (kInjected) {
+        pol = pair_from_global(p.t_root_policy + (size_t)g * A, A, lane);
+    } else {
+        for (int k = lane; k < m.obs_dim; k += kWave) L.xh[k] = p.obs[(size_t)g * m.obs_dim + k];
+        wave_sync();
+        model_representation(m, L, hid_g, lane);
+        (void)model_prediction(m, L, &pol, lane);
+    }
+    wave_expand(c, L, 0, 0, 0.0f, pol, lane);
+    /* add_exploration_noise_at_the_root (mcts.py:134-145): f32 product widened, f64 sum */
+    if (lane < A) {
+        const float pr = L.nodes[1 + lane].prior;
+        if (p.train && S > 0)
+            s.root_prior = (double)(pr * p.omf32) + p.dirichlet[(size_t)g * A + lane] * p.frac;
+        else
+            s.root_prior = (double)pr;
+    }
+
+    for (int sim = 0; sim < S; ++sim) {
+        int depth, action, pbase;
+        const int leaf = wave_select(c, s, L, &depth, &action, &pbase, lane);
+        const int e_new = sim + 1;
+        float reward, value;
+        if (kInjected) {
+            reward = p.t_reward[(size_t)g * S + sim];
+            value = p.t_value[(size_t)g * S + sim];
+            pol = pair_from_global(p.t_prior + ((size_t)g * S + sim) * A, A, lane);
+        } else {
+            /* dynamics on the parent's hidden state, prediction on the new one (mcts.py:180-192) */
+            const int e_parent = (pbase - 1) / A;
+            const float* hp = hid_g + (size_t)e_parent * p.t.hid_stride;
+            for (int k = lane; k < m.Sd; k += kWave) L.xh[k] = hp[k];
+            wave_sync();
+            reward = model_dynamics(m, L, action, hid_g + (size_t)e_new * p.t.hid_stride, lane);
+            value = model_prediction(m, L, &pol, lane);
+        }
+        wave_expand(c, L, leaf, e_new, reward, pol, lane);
+        if (lane == 0) p.t.sim_leaf[(size_t)g * p.t.max_sims + sim] = leaf;
+        wave_backup(c, s, L, depth, value, lane);
+    }
+
+    /* tree -> HBM structure of arrays; results (mcts.py:215-222) */
+    const size_t row = (size_t)g * p.t.stride;
+    for (int n = lane; n < p.n_nodes; n += kWave) {
+        const Node nd = L.nodes[n];
+        p.t.visit[row + n] = nd.visit;
+        p.t.vsum[row + n] = nd.vsum;
+        p.t.prior[row + n] = nd.prior;
+        p.t.reward[row + n] = nd.reward;
+        p.t.child_base[row + n] = L.cb[n];
+    }
+    if (lane < A) {
+        p.r.visits[(size_t)g * A + lane] = L.nodes[1 + lane].visit;
+        p.r.root_prior[(size_t)g * A + lane] = s.root_prior;
+    }
+    if (lane == 0) {
+        const Node r = L.nodes[0];
+        p.r.root_value[g] = r.visit == 0 ? 0.0f : r.vsum / (float)r.visit;
+        p.r.consumed[g] = s.consumed;
+        p.r.path_len[g] = s.path_total;
+        p.t.minmax[2 * (size_t)g] = s.mn;
+        p.t.minmax[2 * (size_t)g + 1] = s.mx;
+        p.t.status[g] = s.status;
+    }
+}
+
+/* ------------------------------------------------------------------------------
+ * Standalone batched inference (wave per sample): the Muzero.*_inference wrappers
+ * (muzero_model.py:828-905).
+ * ---------------------------------------------------------------------------- */
+struct InferParams {
+    Model m;
+    LdsLayout lds;
+    int batch;
+    const float* in;       /* obs [B][obs_dim] or hidden [B][Sd] */
+    const int* action;     /* [B]                                */
+    float* reward;         /* [B]                                */
+    float* hidden_out;     /* [B][Sd]                            */
+    float* policy;         /* [B][A]                             */
+    float* value;          /* [B]                                */
+};
+
+enum { kInferInitial = 0, kInferRecurrent = 1, kInferPrediction = 2 };
+
+template <int kMode>
+__global__ void __launch_bounds__(256) k_inference(const InferParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int b = blockIdx.x * (blockDim.x >> 6) + wave;
+    if (b >= p.batch) return;
+    const WaveLds L = carve(smem + (size_t)wave * p.lds.bytes, p.lds);
+    const Model& m = p.m;
+    const int n_in = kMode == kInferInitial ? m.obs_dim : m.Sd;
+    for (int k = lane; k < n_in; k += kWave) L.xh[k] = p.in[(size_t)b * n_in + k];
+    wave_sync();
+    if (kMode == kInferInitial) {
+        model_representation(m, L, nullptr, lane);
+    } else if (kMode == kInferRecurrent) {
+        const float reward = model_dynamics(m, L, p.action[b], nullptr, lane);
+        if (lane == 0) p.reward[b] = reward;
+    }
+    if (kMode != kInferPrediction)
+        for (int k = lane; k < m.Sd; k += kWave) p.hidden_out[(size_t)b * m.Sd + k] = L.xh[k];
+    if (p.policy || p.value) {
+        Pair pol;
+        const float value = model_prediction(m, L, &pol, lane);
+        if (p.policy) pair_to_global(p.policy + (size_t)b * m.A, pol, lane);
+        if (p.value && lane == 0) p.value[b] = value;
+    }
+}
+
+}  // namespace
+
+/* ================================================================== host side */
+
+struct mzs_handle {
+    mzs_config cfg;
+    Model model;
+    LdsLayout lds;
+    TreeArrays tree;
+    Results res;
+    float* w_dev = nullptr;
+    double* pbc_dev = nullptr;
+    size_t w_floats = 0;
+    bool have_weights = false;
+    int n_nodes_max = 0;
+    std::vector<void*> allocs;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(mzs_handle* h, T** out, size_t n) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, n * sizeof(T) + 256));
+    HIP_TRY(hipMemset(p, 0, n * sizeof(T) + 256));
+    h->allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    return MZS_OK;
+}
+
+/* Device weight store: per layer W^T [rows][n_pad] + bias [n_pad] (see mzs_device.h Layer) */
+struct StoreBuilder {
+    std::vector<float> data;
+    Layer add(int rows, int k, int n_pad) {
+        Layer ly;
+        ly.k = k;
+        ly.n_pad = n_pad;
+        ly.w_off = (int)data.size();
+        data.resize(data.size() + (size_t)rows * n_pad, 0.0f);
+        ly.b_off = (int)data.size();
+        data.resize(data.size() + (size_t)n_pad, 0.0f);
+        return ly;
+    }
+    /* W is torch layout [n_out][ld]; copy rows [0,rows) of W^T into columns [col0, col0+n_out) */
+    void fill(const Layer& ly, const float* W, const float* b, int n_out, int rows, int ld, int col0) {
+        for (int j = 0; j < n_out; ++j) {
+            for (int k = 0; k < rows; ++k)
+                data[(size_t)ly.w_off + (size_t)k * ly.n_pad + col0 + j] = W[(size_t)j * ld + k];
+            data[(size_t)ly.b_off + col0 + j] = b[j];
+        }
+    }
+};
+
+void describe_model(const mzs_dims& d, Model* m, StoreBuilder* sb) {
+    const int H = d.hidden_dim, Sd = d.state_dim, A = d.n_actions, HP = round_up(H, 64);
+    m->obs_dim = d.obs_dim;
+    m->A = A;
+    m->Sd = Sd;
+    m->H = H;
+    m->L = d.n_mid_layers;
+    m->seg_state = round_up(Sd, 32);
+    m->seg_value = round_up(A, 32);
+    m->r_in = sb->add(d.obs_dim, d.obs_dim, HP);
+    m->r_mid = sb->add(H, H, HP);
+    m->r_out = sb->add(H, H, round_up(Sd, 64));
+    m->d_in = sb->add(Sd + A, Sd, HP);
+    m->d_mid = sb->add(H, H, HP);
+    m->d_heads = sb->add(H, H, round_up(m->seg_state + Sd, 64));
+    m->p_in = sb->add(Sd, Sd, HP);
+    m->p_mid = sb->add(H, H, HP);
+    m->p_heads = sb->add(H, H, round_up(m->seg_value + Sd, 64));
+}
+
+LdsLayout make_lds_layout(const Model& m, int n_nodes, int S) {
+    LdsLayout l;
+    int off = round_up(n_nodes * (int)sizeof(Node), 16);
+    l.off_cb = off;
+    off += round_up(n_nodes * 2, 16);
+    l.off_path = off;
+    off += round_up((S + 2) * 2, 16);
+    l.off_xh = off;
+    off += round_up((m.obs_dim > m.Sd ? m.obs_dim : m.Sd) * 4, 16);
+    l.off_xa = off;
+    off += round_up(m.H, 64) * 4;
+    l.off_xb = off;
+    off += round_up(m.H, 64) * 4;
+    l.off_ob = off;
+    int ob = m.r_out.n_pad;
+    ob = m.d_heads.n_pad > ob ? m.d_heads.n_pad : ob;
+    ob = m.p_heads.n_pad > ob ? m.p_heads.n_pad : ob;
+    off += ob * 4;
+    l.bytes = round_up(off, 16);
+    return l;
+}
+
+constexpr int kMaxLdsPerBlock = 160 * 1024;
+
+/* waves per block so that the block's LDS fits; 0 if even one wave does not */
+int waves_per_block(const LdsLayout& l) {
+    int w = 4;
+    while (w > 0 && w * l.bytes > kMaxLdsPerBlock) --w;
+    return w;
+}
+
+template <typename K, typename P>
+int launch(K kernel, const P& params, int units, const LdsLayout& lds, hipStream_t st) {
+    const int wpb = waves_per_block(lds);
+    if (wpb == 0) return fail(MZS_E_ARG, "problem too large for one wave's LDS slice");
+    const int blocks = (units + wpb - 1) / wpb;
+    const size_t shmem = (size_t)wpb * lds.bytes;
+    if (shmem > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(wpb * kWave), shmem, st, params);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
+int check_search_args(mzs_handle* h, int n_games, int S, int train, const double* dirichlet,
+                      const double* noise, int64_t stride) {
+    if (!h) return fail(MZS_E_ARG, "null handle");
+    if (n_games < 0 || n_games > h->cfg.max_games)
+        return fail(MZS_E_ARG, "n_games exceeds max_games of the handle");
+    if (S < 0 || S > h->cfg.max_simulations)
+        return fail(MZS_E_ARG, "num_simulations exceeds max_simulations of the handle");
+    if (S > 0 && (!noise || stride < mzs_max_draws(h->cfg.dims.n_actions, S)))
+        return fail(MZS_E_ARG, "noise stream missing or shorter than mzs_max_draws(A, S)");
+    if (S > 0 && train && !dirichlet) return fail(MZS_E_ARG, "train=1 needs dirichlet_dev");
+    return MZS_OK;
+}
+
+void fill_search_params(mzs_handle* h, SearchParams* p, int n_games, int S, int train,
+                        const double* dirichlet, const double* noise, int64_t stride) {
+    std::memset(p, 0, sizeof(*p));
+    p->m = h->model;
+    p->n_nodes = mzs_nodes_per_game(h->cfg.dims.n_actions, S);
+    p->lds = make_lds_layout(h->model, p->n_nodes, S);
+    p->t = h->tree;
+    p->r = h->res;
+    p->n_games = n_games;
+    p->S = S;
+    p->train = train;
+    p->g32 = (float)h->cfg.discount;
+    p->omf32 = (float)(1.0 - h->cfg.root_exploration_fraction);
+    p->frac = h->cfg.root_exploration_fraction;
+    p->pbc = h->pbc_dev;
+    p->dirichlet = dirichlet;
+    p->noise = S > 0 ? noise : nullptr;
+    p->noise_stride = stride;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mzs_last_error(void) { return g_err.c_str(); }
+const char* mzs_version(void) { return "mzsearch 0.1 (gfx950)"; }
+
+size_t mzs_weight_count(const mzs_dims* dims) {
+    if (!dims) return 0;
+    return mzs_blob_layout(dims).total;
+}
+
+int mzs_create(const mzs_config* cfg, mzs_handle** out) {
+    if (!cfg || !out) return fail(MZS_E_ARG, "null argument");
+    const mzs_dims& d = cfg->dims;
+    if (d.obs_dim < 1 || d.n_actions < 1 || d.state_dim < 1 || d.hidden_dim < 1 ||
+        d.n_mid_layers < 0)
+        return fail(MZS_E_ARG, "dims must be positive");
+    if (d.n_actions > 64) return fail(MZS_E_ARG, "n_actions > 64 not supported (one lane per child)");
+    if (d.state_dim > 128) return fail(MZS_E_ARG, "state_dim > 128 not supported (two logits per lane)");
+    if (cfg->max_games < 1 || cfg->max_simulations < 0) return fail(MZS_E_ARG, "bad sizes");
+    if (mzs_nodes_per_game(d.n_actions, cfg->max_simulations) > 65535)
+        return fail(MZS_E_ARG, "tree exceeds 65535 nodes per game");
+    if (cfg->max_simulations > 0 && !cfg->pbc_table) return fail(MZS_E_ARG, "pbc_table is null");
+    if (cfg->engine != MZS_ENGINE_FUSED)
+        return fail(MZS_E_ARG, "unknown engine");
+    HIP_TRY(hipSetDevice(cfg->device));
+    mzs_handle* h = new (std::nothrow) mzs_handle();
+    if (!h) return fail(MZS_E_ARG, "out of host memory");
+    h->cfg = *cfg;
+    h->cfg.pbc_table = nullptr;
+    StoreBuilder sb;
+    describe_model(d, &h->model, &sb);
+    h->w_floats = sb.data.size();
+    h->n_nodes_max = mzs_nodes_per_game(d.n_actions, cfg->max_simulations);
+    h->lds = make_lds_layout(h->model, h->n_nodes_max, cfg->max_simulations);
+    if (waves_per_block(h->lds) == 0) {
+        delete h;
+        return fail(MZS_E_ARG, "tree + activations of one game exceed 160 KiB of LDS");
+    }
+    const size_t G = (size_t)cfg->max_games, Smax = (size_t)cfg->max_simulations;
+    const int A = d.n_actions;
+    h->tree.stride = round_up(h->n_nodes_max, 32);
+    h->tree.hid_stride = round_up(d.state_dim, 32);
+    h->tree.max_sims = cfg->max_simulations;
+    int rc = MZS_OK;
+    const size_t ts = (size_t)h->tree.stride;
+    if ((rc = dev_alloc(h, &h->w_dev, h->w_floats)) ||
+        (rc = dev_alloc(h, &h->pbc_dev, Smax + 2)) ||
+        (rc = dev_alloc(h, &h->tree.visit, G * ts)) ||
+        (rc = dev_alloc(h, &h->tree.vsum, G * ts)) ||
+        (rc = dev_alloc(h, &h->tree.prior, G * ts)) ||
+        (rc = dev_alloc(h, &h->tree.reward, G * ts)) ||
+        (rc = dev_alloc(h, &h->tree.child_base, G * ts)) ||
+        (rc = dev_alloc(h, &h->tree.sim_leaf, G * (Smax + 1))) ||
+        (rc = dev_alloc(h, &h->tree.minmax, G * 2)) ||
+        (rc = dev_alloc(h, &h->tree.hidden, G * (Smax + 1) * h->tree.hid_stride)) ||
+        (rc = dev_alloc(h, &h->tree.status, G)) ||
+        (rc = dev_alloc(h, &h->res.visits, G * A)) ||
+        (rc = dev_alloc(h, &h->res.root_value, G)) ||
+        (rc = dev_alloc(h, &h->res.root_prior, G * A)) ||
+        (rc = dev_alloc(h, &h->res.consumed, G)) ||
+        (rc = dev_alloc(h, &h->res.path_len, G))) {
+        mzs_destroy(h);
+        return rc;
+    }
+    if (cfg->max_simulations > 0) {
+        hipError_t e = hipMemcpy(h->pbc_dev, cfg->pbc_table, (Smax + 1) * sizeof(double),
+                                 hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            mzs_destroy(h);
+            return fail(MZS_E_HIP, std::string("pbc_table upload: ") + hipGetErrorString(e));
+        }
+    }
+    h->model.w = h->w_dev;
+    *out = h;
+    return MZS_OK;
+}
+
+void mzs_destroy(mzs_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->cfg.device);
+    for (void* p : h->allocs) (void)hipFree(p);
+    delete h;
+}
+
+int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats) {
+    if (!h || !blob) return fail(MZS_E_ARG, "null argument");
+    const mzs_dims& d = h->cfg.dims;
+    const mzs_blob_offsets o = mzs_blob_layout(&d);
+    if (n_floats != o.total) {
+        char msg[128];
+        std::snprintf(msg, sizeof msg, "weight blob has %zu floats, expected %zu", n_floats, o.total);
+        return fail(MZS_E_ARG, msg);
+    }
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    std::vector<float> host(n_floats);
+    HIP_TRY(hipMemcpy(host.data(), blob, n_floats * sizeof(float), hipMemcpyDefault));
+    const float* B = host.data();
+    const int H = d.hidden_dim, Sd = d.state_dim, A = d.n_actions, ob = d.obs_dim;
+    StoreBuilder sb;
+    Model m;
+    describe_model(d, &m, &sb);
+    sb.fill(m.r_in, B + o.r_in_w, B + o.r_in_b, H, ob, ob, 0);
+    sb.fill(m.r_out, B + o.r_out_w, B + o.r_out_b, Sd, H, H, 0);
+    sb.fill(m.d_in, B + o.d_in_w, B + o.d_in_b, H, Sd + A, Sd + A, 0);
+    sb.fill(m.d_heads, B + o.d_rew_w, B + o.d_rew_b, Sd, H, H, 0);
+    sb.fill(m.d_heads, B + o.d_st_w, B + o.d_st_b, Sd, H, H, m.seg_state);
+    sb.fill(m.p_in, B + o.p_in_w, B + o.p_in_b, H, Sd, Sd, 0);
+    sb.fill(m.p_heads, B + o.p_pol_w, B + o.p_pol_b, A, H, H, 0);
+    sb.fill(m.p_heads, B + o.p_val_w, B + o.p_val_b, Sd, H, H, m.seg_value);
+    if (d.n_mid_layers > 0) {
+        sb.fill(m.r_mid, B + o.r_mid_w, B + o.r_mid_b, H, H, H, 0);
+        sb.fill(m.d_mid, B + o.d_mid_w, B + o.d_mid_b, H, H, H, 0);
+        sb.fill(m.p_mid, B + o.p_mid_w, B + o.p_mid_b, H, H, H, 0);
+    }
+    HIP_TRY(hipMemcpy(h->w_dev, sb.data.data(), sb.data.size() * sizeof(float),
+                      hipMemcpyHostToDevice));
+    h->have_weights = true;
+    return MZS_OK;
+}
+
+int mzs_search(mzs_handle* h, int32_t n_games, int32_t S, int32_t train, const float* obs_dev,
+               const double* dirichlet_dev, const double* noise_dev, int64_t noise_stride,
+               void* stream) {
+    int rc = check_search_args(h, n_games, S, train, dirichlet_dev, noise_dev, noise_stride);
+    if (rc) return rc;
+    if (!h->have_weights) return fail(MZS_E_STATE, "mzs_set_weights has not been called");
+    if (!obs_dev) return fail(MZS_E_ARG, "obs_dev is null");
+    if (n_games == 0) return MZS_OK;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    SearchParams p;
+    fill_search_params(h, &p, n_games, S, train, dirichlet_dev, noise_dev, noise_stride);
+    p.obs = obs_dev;
+    return launch(k_search_fused<false>, p, n_games, p.lds, static_cast<hipStream_t>(stream));
+}
+
+int mzs_search_injected(mzs_handle* h, int32_t n_games, int32_t S, int32_t train,
+                        const float* root_policy_dev, const float* sim_reward_dev,
+                        const float* sim_value_dev, const float* sim_prior_dev,
+                        const double* dirichlet_dev, const double* noise_dev,
+                        int64_t noise_stride, void* stream) {
+    int rc = check_search_args(h, n_games, S, train, dirichlet_dev, noise_dev, noise_stride);
+    if (rc) return rc;
+    if (!root_policy_dev || (S > 0 && (!sim_reward_dev || !sim_value_dev || !sim_prior_dev)))
+        return fail(MZS_E_ARG, "injected model tables are null");
+    if (n_games == 0) return MZS_OK;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    SearchParams p;
+    fill_search_params(h, &p, n_games, S, train, dirichlet_dev, noise_dev, noise_stride);
+    p.t_root_policy = root_policy_dev;
+    p.t_reward = sim_reward_dev;
+    p.t_value = sim_value_dev;
+    p.t_prior = sim_prior_dev;
+    return launch(k_search_fused<true>, p, n_games, p.lds, static_cast<hipStream_t>(stream));
+}
+
+int mzs_results(mzs_handle* h, int32_t n_games, int32_t* visits_dev, float* root_value_dev,
+                double* root_prior_dev, int64_t* consumed_dev, int64_t* path_len_dev,
+                void* stream) {
+    if (!h) return fail(MZS_E_ARG, "null handle");
+    if (n_games < 0 || n_games > h->cfg.max_games) return fail(MZS_E_ARG, "bad n_games");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const size_t G = (size_t)n_games, A = (size_t)h->cfg.dims.n_actions;
+    if (visits_dev)
+        HIP_TRY(hipMemcpyAsync(visits_dev, h->res.visits, G * A * 4, hipMemcpyDeviceToDevice, st));
+    if (root_value_dev)
+        HIP_TRY(hipMemcpyAsync(root_value_dev, h->res.root_value, G * 4, hipMemcpyDeviceToDevice, st));
+    if (root_prior_dev)
+        HIP_TRY(hipMemcpyAsync(root_prior_dev, h->res.root_prior, G * A * 8, hipMemcpyDeviceToDevice, st));
+    if (consumed_dev)
+        HIP_TRY(hipMemcpyAsync(consumed_dev, h->res.consumed, G * 8, hipMemcpyDeviceToDevice, st));
+    if (path_len_dev)
+        HIP_TRY(hipMemcpyAsync(path_len_dev, h->res.path_len, G * 8, hipMemcpyDeviceToDevice, st));
+    return MZS_OK;
+}
+
+void* mzs_tree_array(mzs_handle* h, int32_t which) {
+    if (!h) return nullptr;
+    switch (which) {
+        case MZS_TREE_VISIT: return h->tree.visit;
+        case MZS_TREE_VALUE_SUM: return h->tree.vsum;
+        case MZS_TREE_PRIOR: return h->tree.prior;
+        case MZS_TREE_REWARD: return h->tree.reward;
+        case MZS_TREE_CHILD_BASE: return h->tree.child_base;
+        case MZS_TREE_SIM_LEAF: return h->tree.sim_leaf;
+        case MZS_TREE_MINMAX: return h->tree.minmax;
+        case MZS_TREE_HIDDEN: return h->tree.hidden;
+        case MZS_TREE_STATUS: return h->tree.status;
+        default: return nullptr;
+    }
+}
+
+int32_t mzs_tree_stride(const mzs_handle* h) { return h ? h->tree.stride : 0; }
+int32_t mzs_hidden_stride(const mzs_handle* h) { return h ? h->tree.hid_stride : 0; }
+
+static int run_inference(mzs_handle* h, int mode, int32_t batch, const float* in,
+                         const int32_t* action, float* reward, float* hidden_out, float* policy,
+                         float* value, void* stream) {
+    if (!h) return fail(MZS_E_ARG, "null handle");
+    if (!h->have_weights) return fail(MZS_E_STATE, "mzs_set_weights has not been called");
+    if (batch < 0 || !in) return fail(MZS_E_ARG, "bad batch or null input");
+    if (mode != kInferPrediction && !hidden_out) return fail(MZS_E_ARG, "hidden output is null");
+    if (mode == kInferRecurrent && (!action || !reward)) return fail(MZS_E_ARG, "null action/reward");
+    if (batch == 0) return MZS_OK;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    InferParams p;
+    std::memset(&p, 0, sizeof p);
+    p.m = h->model;
+    p.lds = make_lds_layout(h->model, 1, 0);
+    p.batch = batch;
+    p.in = in;
+    p.action = action;
+    p.reward = reward;
+    p.hidden_out = hidden_out;
+    p.policy = policy;
+    p.value = value;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (mode == kInferInitial) return launch(k_inference<kInferInitial>, p, batch, p.lds, st);
+    if (mode == kInferRecurrent) return launch(k_inference<kInferRecurrent>, p, batch, p.lds, st);
+    return launch(k_inference<kInferPrediction>, p, batch, p.lds, st);
+}
+
+int mzs_initial_inference(mzs_handle* h, int32_t batch, const float* obs_dev, float* hidden_dev,
+                          float* policy_dev, float* value_dev, void* stream) {
+    return run_inference(h, kInferInitial, batch, obs_dev, nullptr, nullptr, hidden_dev, policy_dev,
+                         value_dev, stream);
+}
+
+int mzs_recurrent_inference(mzs_handle* h, int32_t batch, const float* hidden_dev,
+                            const int32_t* action_dev, float* reward_dev, float* next_hidden_dev,
+                            float* policy_dev, float* value_dev, void* stream) {
+    return run_inference(h, kInferRecurrent, batch, hidden_dev, action_dev, reward_dev,
+                         next_hidden_dev, policy_dev, value_dev, stream);
+}
+
+int mzs_prediction_inference(mzs_handle* h, int32_t batch, const float* hidden_dev,
+                             float* policy_dev, float* value_dev, void* stream) {
+    if (!policy_dev && !value_dev) return fail(MZS_E_ARG, "no output requested");
+    return run_inference(h, kInferPrediction, batch, hidden_dev, nullptr, nullptr, nullptr,
+                         policy_dev, value_dev, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,223 @@
+"""SearchEngine — thin owner of one mzs_handle (one GPU, one stream).
+
+Device memory, streams and host<->device copies come from PyTorch-ROCm; all
+compute goes through the C-ABI of libmzsearch.so (include/mzsearch.h).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib, rng
+
+
+class _DevView:
+    """Expose a raw device pointer of the handle to torch (CUDA array interface)."""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr,
+                                         "data": (int(ptr), False), "version": 2}
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    return C.c_void_p(t.data_ptr())
+
+
+class SearchEngine:
+    """Batched Monte_carlo_tree_search over `max_games` concurrent games.
+
+    dims = (obs_dim, n_actions, state_dim, hidden_dim, n_mid_layers) — the shapes the
+    reference passes to Muzero(...) (muzero_model.py:16-35); discount / pb_c_* /
+    root_exploration_fraction are the Monte_carlo_tree_search ctor arguments
+    (monte_carlo_tree_search.py:38).
+    """
+
+    def __init__(self, dims, max_games, max_simulations, discount=0.95,
+                 root_exploration_fraction=0.25, pb_c_base=19652, pb_c_init=1.25,
+                 root_dirichlet_alpha=0.25, device=0, engine=_lib.ENGINE_FUSED):
+        if not torch.cuda.is_available():
+            raise _lib.MzsError("no GPU visible: the search path has no CPU fallback")
+        self.lib = _lib.load()
+        self.dims = tuple(int(x) for x in dims)
+        self.obs_dim, self.A, self.S_dim, self.H, self.L = self.dims
+        self.max_games, self.max_simulations = int(max_games), int(max_simulations)
+        self.discount = float(discount)
+        self.frac = float(root_exploration_fraction)
+        self.alpha = float(root_dirichlet_alpha)
+        self.pb_c_base, self.pb_c_init = pb_c_base, pb_c_init
+        self.device = torch.device("cuda", int(device))
+        self.pbc = rng.pbc_table(self.max_simulations, pb_c_base, pb_c_init)
+        cfg = _lib.Config(_lib.Dims(*self.dims), self.max_games, self.max_simulations,
+                          int(device), int(engine), self.discount, self.frac,
+                          self.pbc.ctypes.data_as(C.c_void_p))
+        h = C.c_void_p()
+        _lib.check(self.lib.mzs_create(C.byref(cfg), C.byref(h)), "mzs_create")
+        self.h = h
+        self.n_games = 0
+        self.num_simulations = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mzs_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    # ------------------------------------------------------------------ weights
+    def weight_count(self):
+        d = _lib.Dims(*self.dims)
+        return int(self.lib.mzs_weight_count(C.byref(d)))
+
+    def set_weights(self, blob):
+        """blob: packed fp32 weights (include/mzs_layout.h), numpy array or torch tensor."""
+        if isinstance(blob, torch.Tensor):
+            t = blob.detach().to(torch.float32).contiguous()
+            ptr, n = C.c_void_p(t.data_ptr()), t.numel()
+            if t.is_cuda:
+                torch.cuda.synchronize(t.device)
+        else:
+            t = np.ascontiguousarray(blob, dtype=np.float32)
+            ptr, n = t.ctypes.data_as(C.c_void_p), t.size
+        _lib.check(self.lib.mzs_set_weights(self.h, ptr, n), "mzs_set_weights")
+
+    # ------------------------------------------------------------------- search
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, dtype):
+        if a is None:
+            return None
+        if isinstance(a, torch.Tensor):
+            return a.to(device=self.device, dtype=dtype).contiguous()
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
+
+    def search(self, obs, dirichlet, noise, num_simulations, train=True):
+        """Enqueue one search per row of `obs` on the current stream (no host sync).
+        obs [G, obs_dim] f32, dirichlet [G, A] f64 or None, noise [G, stride] f64."""
+        obs = self._dev(obs, torch.float32)
+        dirichlet = self._dev(dirichlet, torch.float64)
+        noise = self._dev(noise, torch.float64)
+        G = obs.shape[0]
+        assert obs.shape == (G, self.obs_dim)
+        stride = 0 if noise is None else noise.shape[1]
+        if noise is not None:
+            assert noise.shape[0] == G
+        if dirichlet is not None:
+            assert dirichlet.shape == (G, self.A)
+        self._keep = (obs, dirichlet, noise)
+        _lib.check(self.lib.mzs_search(self.h, G, int(num_simulations), int(bool(train)),
+                                       _ptr(obs), _ptr(dirichlet), _ptr(noise), stride,
+                                       self._stream()), "mzs_search")
+        self.n_games, self.num_simulations = G, int(num_simulations)
+
+    def search_injected(self, table, dirichlet, noise, num_simulations, train=True):
+        """L1 mode: `table` = dict(root_policy [G,A], sim_reward [G,S], sim_value [G,S],
+        sim_prior [G,S,A]) holds the model outputs to use instead of computing them."""
+        tb = {k: self._dev(table[k], torch.float32)
+              for k in ("root_policy", "sim_reward", "sim_value", "sim_prior")}
+        dirichlet = self._dev(dirichlet, torch.float64)
+        noise = self._dev(noise, torch.float64)
+        G = tb["root_policy"].shape[0]
+        stride = 0 if noise is None else noise.shape[1]
+        self._keep = (tb, dirichlet, noise)
+        _lib.check(self.lib.mzs_search_injected(
+            self.h, G, int(num_simulations), int(bool(train)), _ptr(tb["root_policy"]),
+            _ptr(tb["sim_reward"]), _ptr(tb["sim_value"]), _ptr(tb["sim_prior"]),
+            _ptr(dirichlet), _ptr(noise), stride, self._stream()), "mzs_search_injected")
+        self.n_games, self.num_simulations = G, int(num_simulations)
+
+    def results(self):
+        """Device tensors: visits i32 [G,A], root_value f32 [G], root_prior f64 [G,A],
+        consumed i64 [G], path_len i64 [G] (enqueued copies; caller synchronises)."""
+        G, A, dev = self.n_games, self.A, self.device
+        out = dict(visits=torch.empty((G, A), dtype=torch.int32, device=dev),
+                   root_value=torch.empty(G, dtype=torch.float32, device=dev),
+                   root_prior=torch.empty((G, A), dtype=torch.float64, device=dev),
+                   consumed=torch.empty(G, dtype=torch.int64, device=dev),
+                   path_len=torch.empty(G, dtype=torch.int64, device=dev))
+        _lib.check(self.lib.mzs_results(self.h, G, _ptr(out["visits"]), _ptr(out["root_value"]),
+                                        _ptr(out["root_prior"]), _ptr(out["consumed"]),
+                                        _ptr(out["path_len"]), self._stream()), "mzs_results")
+        return out
+
+    def results_host(self):
+        out = self.results()
+        torch.cuda.synchronize(self.device)
+        return {k: v.cpu().numpy() for k, v in out.items()}
+
+    def tree(self):
+        """Zero-copy torch views of the handle's SoA tree (valid until the next search)."""
+        G, Smax = self.max_games, self.max_simulations
+        st = int(self.lib.mzs_tree_stride(self.h))
+        hs = int(self.lib.mzs_hidden_stride(self.h))
+        spec = dict(visit=(_lib.TREE_VISIT, (G, st), "<i4"),
+                    value_sum=(_lib.TREE_VALUE_SUM, (G, st), "<f4"),
+                    prior=(_lib.TREE_PRIOR, (G, st), "<f4"),
+                    reward=(_lib.TREE_REWARD, (G, st), "<f4"),
+                    child_base=(_lib.TREE_CHILD_BASE, (G, st), "<i4"),
+                    sim_leaf=(_lib.TREE_SIM_LEAF, (G, max(Smax, 1)), "<i4"),
+                    minmax=(_lib.TREE_MINMAX, (G, 2), "<f4"),
+                    hidden=(_lib.TREE_HIDDEN, (G, Smax + 1, hs), "<f4"),
+                    status=(_lib.TREE_STATUS, (G,), "<i4"))
+        out = {}
+        for k, (which, shape, ts) in spec.items():
+            p = self.lib.mzs_tree_array(self.h, which)
+            out[k] = torch.as_tensor(_DevView(p, shape, ts), device=self.device)
+        return out
+
+    def tree_host(self):
+        torch.cuda.synchronize(self.device)
+        n = 1 + self.A * (self.num_simulations + 1)
+        t = {k: v[: self.n_games].cpu().numpy() for k, v in self.tree().items()}
+        for k in ("visit", "value_sum", "prior", "reward", "child_base"):
+            t[k] = t[k][:, :n]
+        t["sim_leaf"] = t["sim_leaf"][:, : self.num_simulations]
+        t["hidden"] = t["hidden"][:, : self.num_simulations + 1, : self.S_dim]
+        return t
+
+    def run_batch(self, observations, seeds=None, num_simulations=None, train=True,
+                  dirichlet=None, noise=None):
+        """Convenience wrapper: draw per-game streams from `seeds` (RandomState(seed):
+        Dirichlet, then the tie-break uniforms — what the reference's global stream yields
+        after np.random.seed(seed)), search, and return host arrays."""
+        S = self.max_simulations if num_simulations is None else int(num_simulations)
+        if noise is None:
+            dirichlet, noise = rng.noise_streams(seeds, self.A, S, self.alpha, train)
+        self.search(observations, dirichlet if (train and S > 0) else None,
+                    noise if S > 0 else None, S, train)
+        return self.results_host()
+
+    # ---------------------------------------------------------------- inference
+    def initial_inference(self, obs, want_prediction=True):
+        obs = self._dev(obs, torch.float32)
+        B = obs.shape[0]
+        hid = torch.empty((B, self.S_dim), dtype=torch.float32, device=self.device)
+        pol = torch.empty((B, self.A), dtype=torch.float32, device=self.device) if want_prediction else None
+        val = torch.empty(B, dtype=torch.float32, device=self.device) if want_prediction else None
+        _lib.check(self.lib.mzs_initial_inference(self.h, B, _ptr(obs), _ptr(hid), _ptr(pol),
+                                                  _ptr(val), self._stream()), "mzs_initial_inference")
+        return hid, pol, val
+
+    def recurrent_inference(self, hidden, action, want_prediction=True):
+        hidden = self._dev(hidden, torch.float32)
+        action = self._dev(action, torch.int32)
+        B = hidden.shape[0]
+        rew = torch.empty(B, dtype=torch.float32, device=self.device)
+        nh = torch.empty((B, self.S_dim), dtype=torch.float32, device=self.device)
+        pol = torch.empty((B, self.A), dtype=torch.float32, device=self.device) if want_prediction else None
+        val = torch.empty(B, dtype=torch.float32, device=self.device) if want_prediction else None
+        _lib.check(self.lib.mzs_recurrent_inference(self.h, B, _ptr(hidden), _ptr(action), _ptr(rew),
+                                                    _ptr(nh), _ptr(pol), _ptr(val), self._stream()),
+                   "mzs_recurrent_inference")
+        return rew, nh, pol, val
+
+    def prediction_inference(self, hidden):
+        hidden = self._dev(hidden, torch.float32)
+        B = hidden.shape[0]
+        pol = torch.empty((B, self.A), dtype=torch.float32, device=self.device)
+        val = torch.empty(B, dtype=torch.float32, device=self.device)
+        _lib.check(self.lib.mzs_prediction_inference(self.h, B, _ptr(hidden), _ptr(pol), _ptr(val),
+                                                     self._stream()), "mzs_prediction_inference")
+        return pol, val

@@ -27,12 +27,12 @@ static void elu_inplace(float* x, int n) {
     for (int i = 0; i < n; ++i) x[i] = mzs_elu(x[i]);
 }
 
-/* contract "sum": halving tree over the zero-padded array (clobbers v[0..P)) */
+/* contract "sum": adjacent-pair tree over the zero-padded array (clobbers v[0..P)) */
 static float tree_sum(float* v, int n) {
     int P = mzs_pow2_ceil(n);
     for (int i = n; i < P; ++i) v[i] = 0.0f;
-    for (int off = P >> 1; off >= 1; off >>= 1)
-        for (int i = 0; i < off; ++i) v[i] = v[i] + v[i + off];
+    for (int len = P; len > 1; len >>= 1)
+        for (int i = 0; i < len / 2; ++i) v[i] = v[2 * i] + v[2 * i + 1];
     return v[0];
 }
 

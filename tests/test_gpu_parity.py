@@ -1,0 +1,174 @@
+"""GPU parity tests: HIP path (through the C-ABI) vs the CPU oracle and the golden
+fixtures recorded from the reference.  Run on the MI355X box: pytest -m gpu.
+
+Bars (north_star): visit counts / expanded leaves / draws consumed bit-exact; with
+the arithmetic contract of include/mzs_numeric.h the fp32 outputs are bit-exact
+against the oracle as well (compared as raw bits), and within 1e-5 relative of the
+reference fixtures (value scalars: plus one quantum of the reference's own fp32
+inverse transform, see tests/test_oracle_golden.py::value_err).
+"""
+import numpy as np
+import pytest
+
+from conftest import (MODEL_TAGS, SEARCH_FIXTURES, fixture_streams, fixture_weights, load_golden)
+from test_oracle_golden import MARGIN_TAU, REL, hidden_err, leaves_of, rel_err, table_of, value_err
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    a = np.ascontiguousarray(a)
+    return a.view(np.uint32) if a.dtype == np.float32 else a.view(np.uint64) if a.dtype == np.float64 else a
+
+
+def same_bits(a, b):
+    return np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
+
+
+def make_engine(d, G, S, gamma, frac=0.25):
+    from muzero_amd.engine import SearchEngine
+    return SearchEngine((d.obs_dim, d.n_actions, d.state_dim, d.hidden_dim, d.n_mid_layers),
+                        max_games=G, max_simulations=S, discount=gamma,
+                        root_exploration_fraction=frac)
+
+
+@pytest.mark.parametrize("fname,tag", SEARCH_FIXTURES)
+def test_L1_search_injected_bit_exact(fname, tag):
+    """Search kernels alone: the reference's own model outputs injected."""
+    fx = load_golden(fname)
+    d, _ = fixture_weights(tag)
+    S, G = int(fx["S"]), len(fx["seed"])
+    dirichlet, noise = fixture_streams(fx)
+    eng = make_engine(d, G, S, float(fx["gamma"]), float(fx["frac"]))
+    assert np.array_equal(eng.pbc[: S + 1], fx["pbc_table"][: S + 1])
+    train = bool(fx["train"])
+    eng.search_injected(table_of(fx), dirichlet if train and S > 0 else None,
+                        noise if S > 0 else None, S, train)
+    out = eng.results_host()
+    tree = eng.tree_host()
+    if S > 0:
+        assert np.array_equal(out["visits"].astype(np.float64), fx["visits"])
+    assert same_bits(out["root_prior"], fx["root_prior"])
+    assert same_bits(out["root_value"], fx["root_value"])
+    assert np.array_equal(out["consumed"], fx["n_draws"])
+    assert np.array_equal(out["path_len"], fx["total_path_len"])
+    assert np.array_equal(tree["sim_leaf"], leaves_of(fx))
+    assert np.array_equal(tree["visit"], fx["child_visit"])
+    assert same_bits(tree["value_sum"], fx["child_vsum"])
+    assert not tree["status"].any()
+    eng.close()
+
+
+@pytest.mark.parametrize("tag", MODEL_TAGS)
+def test_L2_inference_kernels(tag):
+    """initial / recurrent / prediction inference: bit-exact vs the oracle, within
+    tolerance of the reference wrappers."""
+    from oracle import mz_oracle as mzo
+    d, blob = fixture_weights(tag)
+    mv = load_golden(f"model_L2_{tag}.npz")
+    eng = make_engine(d, 1, 0, 0.997)
+    eng.set_weights(blob)
+    hid, pol, val = [t.cpu().numpy() for t in eng.initial_inference(mv["obs"])]
+    oh, op, ov = mzo.initial_inference(d, blob, mv["obs"])
+    assert same_bits(hid, oh) and same_bits(pol, op) and same_bits(val, ov)
+    assert hidden_err(hid, mv["repr_hidden"]).max() < REL
+    assert rel_err(pol, mv["ini_policy"]).max() < REL
+    assert value_err(val, mv["ini_value"]).max() <= 1
+    rew, nh, pol, val = [t.cpu().numpy() for t in eng.recurrent_inference(mv["hidden"], mv["action"])]
+    orr, onh, op, ov = mzo.recurrent_inference(d, blob, mv["hidden"], mv["action"])
+    assert same_bits(rew, orr) and same_bits(nh, onh) and same_bits(pol, op) and same_bits(val, ov)
+    assert value_err(rew, mv["dyn_reward"]).max() <= 1
+    assert hidden_err(nh, mv["dyn_hidden"]).max() < REL
+    assert rel_err(pol, mv["rec_policy"]).max() < REL
+    assert value_err(val, mv["rec_value"]).max() <= 1
+    pol, val = [t.cpu().numpy() for t in eng.prediction_inference(mv["hidden"])]
+    op, ov = mzo.prediction(d, blob, mv["hidden"])
+    assert same_bits(pol, op) and same_bits(val, ov)
+    assert rel_err(pol, mv["pred_policy"]).max() < REL
+    assert value_err(val, mv["pred_value"]).max() <= 1
+    eng.close()
+
+
+@pytest.mark.parametrize("fname,tag", SEARCH_FIXTURES)
+def test_L3_search_end_to_end(fname, tag):
+    """Full search on the GPU: bit-exact vs the oracle on every game; vs the reference,
+    identical visit counts on every search without a near-tie."""
+    from oracle import mz_oracle as mzo
+    fx = load_golden(fname)
+    d, blob = fixture_weights(tag)
+    S, G = int(fx["S"]), len(fx["seed"])
+    dirichlet, noise = fixture_streams(fx)
+    train = bool(fx["train"])
+    eng = make_engine(d, G, S, float(fx["gamma"]), float(fx["frac"]))
+    eng.set_weights(blob)
+    eng.search(fx["obs"], dirichlet if train and S > 0 else None, noise if S > 0 else None, S, train)
+    out = eng.results_host()
+    tree = eng.tree_host()
+    ref = mzo.search(d, blob, S, float(fx["gamma"]), float(fx["frac"]), fx["pbc_table"],
+                     obs=fx["obs"], dirichlet=dirichlet, noise=noise, train=train,
+                     want=("visits", "root_value", "root_prior", "consumed", "path_len", "sim_leaf",
+                           "node_visit", "node_vsum", "node_reward", "node_prior", "child_base",
+                           "minmax", "hidden"))
+    assert np.array_equal(out["visits"], ref["visits"])
+    assert same_bits(out["root_value"], ref["root_value"])
+    assert same_bits(out["root_prior"], ref["root_prior"])
+    assert np.array_equal(out["consumed"], ref["consumed"])
+    assert np.array_equal(out["path_len"], ref["path_len"])
+    assert np.array_equal(tree["sim_leaf"], ref["sim_leaf"])
+    assert np.array_equal(tree["visit"], ref["node_visit"])
+    assert np.array_equal(tree["child_base"], ref["child_base"])
+    assert same_bits(tree["value_sum"], ref["node_vsum"])
+    assert same_bits(tree["reward"], ref["node_reward"])
+    assert same_bits(tree["prior"], ref["node_prior"])
+    assert same_bits(tree["minmax"], ref["minmax"])
+    assert same_bits(tree["hidden"], ref["hidden"])
+    # against the reference run itself
+    assert rel_err(out["root_prior"], fx["root_prior"]).max() < REL
+    if S > 0:
+        same = np.all(out["visits"].astype(np.float64) == fx["visits"], axis=1)
+        safe = fx["min_margin"] >= MARGIN_TAU
+        assert np.all(same[safe])
+        assert value_err(out["root_value"][same], fx["root_value"][same]).max() <= 1
+        t0 = np.argmax(out["visits"], axis=1)
+        assert np.array_equal(t0[same], fx["t0_action"][same])
+    eng.close()
+
+
+def test_full_size_4096_games_vs_oracle():
+    """BASELINE config C2: 4096 games x 50 simulations, tag-123 weights, against the
+    oracle on all games (bit-exact), plus size-independent invariants."""
+    from muzero_amd import rng
+    from oracle import mz_oracle as mzo
+    d, blob = fixture_weights("tag123")
+    G, S, A = 4096, 50, 2
+    obs = np.random.RandomState(1000).uniform(-0.05, 0.05, size=(G, 4)).astype(np.float32)
+    dirichlet, noise = rng.noise_streams(np.arange(G), A, S, 0.25, True)
+    eng = make_engine(d, G, S, 0.997)
+    eng.set_weights(blob)
+    eng.search(obs, dirichlet, noise, S, True)
+    out = eng.results_host()
+    tree = eng.tree_host()
+    assert not tree["status"].any()
+    # invariants: every simulation visits exactly one root child; the root is visited S times
+    assert np.all(out["visits"].sum(axis=1) == S)
+    assert np.all(tree["visit"][:, 0] == S)
+    assert np.all(out["consumed"] == A * out["path_len"])
+    # each expanded node's visit count = 1 + sum of its children's
+    cb, vis = tree["child_base"], tree["visit"]
+    for a in range(A):
+        pass
+    exp = cb > 0
+    child_sum = np.zeros_like(vis)
+    gi, ni = np.nonzero(exp)
+    for a in range(A):
+        child_sum[gi, ni] += vis[gi, cb[gi, ni] + a]
+    assert np.all(vis[gi, ni] == child_sum[gi, ni] + (ni > 0))
+    ref = mzo.search(d, blob, S, 0.997, 0.25, eng.pbc, obs=obs, dirichlet=dirichlet, noise=noise,
+                     train=True, n_threads=8,
+                     want=("visits", "root_value", "consumed", "node_vsum", "sim_leaf"))
+    assert np.array_equal(out["visits"], ref["visits"])
+    assert same_bits(out["root_value"], ref["root_value"])
+    assert np.array_equal(out["consumed"], ref["consumed"])
+    assert np.array_equal(tree["sim_leaf"], ref["sim_leaf"])
+    assert same_bits(tree["value_sum"], ref["node_vsum"])
+    eng.close()
