@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — MCTS simulations/sec on the BASELINE.json workload.
+
+One "step" = one batched search: initial inference + S simulations (select,
+recurrent inference, expand, backup) for G games on this rank's GPU, plus the
+result read-back (visit counts / root values to host).  Inputs (observations,
+weights, per-game Dirichlet + tie-break streams) are resident in HBM before the
+timed region.  Games shard over ranks with no collective in the data path.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+F32_MATRIX_PEAK_TFLOPS = 157.3  # fp32 MFMA == fp32 vector peak
+
+
+def algorithmic_bytes_per_sim(A, S_dim, dbar):
+    """select d(24A+8) + expand 8*S_dim+4+16A + backup 20(d+1)."""
+    return dbar * (24 * A + 8) + 8 * S_dim + 4 + 16 * A + 20 * (dbar + 1)
+
+
+def flops_per_sim(A, S_dim, H, L):
+    return 2 * ((S_dim + A) * H + 2 * H * S_dim + S_dim * H + H * A + H * S_dim) + 2 * H * H * 2 * L
+
+
+def cpu_baseline(dims, blob, S, pbc, seconds_target=12.0):
+    """The oracle (CPU restatement, bit-exact to the GPU path) timed on the host cores:
+    a bounded sample of the same workload, 1 thread and up to 16 threads."""
+    from muzero_amd import rng
+    from oracle import mz_oracle as mzo
+    d = mzo.dims(*dims)
+    A = dims[1]
+    n1 = 2048
+    obs = np.random.RandomState(999).uniform(-0.05, 0.05, size=(n1, dims[0])).astype(np.float32)
+    dirichlet, noise = rng.noise_streams(100000 + np.arange(n1), A, S, 0.25, True)
+    kw = dict(obs=obs, dirichlet=dirichlet, noise=noise, train=True, want=("visits",))
+    mzo.search(d, blob, S, 0.997, 0.25, pbc, n_threads=1, **{**kw, "obs": obs[:16],
+               "dirichlet": dirichlet[:16], "noise": noise[:16]})
+    t0 = time.perf_counter()
+    mzo.search(d, blob, S, 0.997, 0.25, pbc, n_threads=1, **kw)
+    t1 = time.perf_counter() - t0
+    rate1 = n1 * S / t1
+    threads = max(1, min(16, os.cpu_count() or 1))
+    reps, tm = 0, 0.0
+    t0 = time.perf_counter()
+    while tm < seconds_target:
+        mzo.search(d, blob, S, 0.997, 0.25, pbc, n_threads=threads, **kw)
+        reps += 1
+        tm = time.perf_counter() - t0
+    cpu_model = "?"
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    cpu_model = line.split(":", 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    return {"value": n1 * reps * S / tm, "unit": "sims/s", "cores": threads, "kind": "port",
+            "value_1thread": rate1,
+            "sample": f"oracle/mz_oracle.c (bit-exact CPU port): {n1} games x {S} sims on 1 thread "
+                      f"({t1:.2f} s), {n1 * reps} games x {S} sims on {threads} threads ({tm:.2f} s)",
+            "cpu": cpu_model}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--games", type=int, default=4096, help="games per GPU")
+    ap.add_argument("--sims", type=int, default=50)
+    ap.add_argument("--weights", default="tag123")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from muzero_amd import rng
+    from muzero_amd.engine import SearchEngine
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+        local_rank = 0
+    dev = torch.device("cuda", local_rank)
+
+    w = np.load(os.path.join(ROOT, "tests", "golden", f"weights_{args.weights}.npz"))
+    dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L"))
+    obs_dim, A, S_dim, H, L = dims
+    G, S = args.games, args.sims
+
+    # synthetic inputs of the BASELINE shape
+    obs = np.random.RandomState(1000 + rank).uniform(-0.05, 0.05, size=(G, obs_dim)).astype(np.float32)
+    dirichlet, noise = rng.noise_streams(rank * G + np.arange(G), A, S, 0.25, True)
+    eng = SearchEngine(dims, G, S, discount=0.997, device=local_rank)
+    eng.set_weights(w["blob"])
+    obs_d = torch.as_tensor(obs).to(dev)
+    dir_d = torch.as_tensor(dirichlet).to(dev)
+    noise_d = torch.as_tensor(noise).to(dev)
+    visits_h = torch.empty((G, A), dtype=torch.int32).pin_memory()
+    value_h = torch.empty(G, dtype=torch.float32).pin_memory()
+
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+
+    def step(i=None):
+        if i is not None:
+            ev0[i].record()
+        eng.search(obs_d, dir_d, noise_d, S, True)       # the search kernel(s), current stream
+        if i is not None:
+            ev1[i].record()
+        res = eng.results()
+        visits_h.copy_(res["visits"], non_blocking=True)
+        value_h.copy_(res["root_value"], non_blocking=True)
+        return res
+
+    def fence():
+        torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    path_len = res["path_len"].cpu().numpy()
+    assert int(visits_h.sum()) == G * S, "search did not complete every simulation"
+    dbar = float(path_len.sum()) / (G * S)
+    sims_per_step = world * G * S
+    value = sims_per_step * args.steps / elapsed
+
+    out = {
+        "metric": "MCTS sims/sec (whole node), CartPole MLP, 50 sims x 4096 games/GPU",
+        "value": value, "unit": "sims/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "data": "synthetic (obs ~ U(-0.05,0.05)^4, tag-123 fixture weights, per-game "
+                "RandomState streams pre-drawn on host and resident in HBM)",
+        "config": {"workload": f"C2: CartPole-v1 MLP obs{obs_dim} A{A} S_dim{S_dim} H{H} L{L}, "
+                               f"{G} games/GPU x {S} sims, fused engine (1 launch per search)",
+                   "games_per_gpu": G, "num_simulations": S, "engine": "fused",
+                   "parallelism": f"games sharded over {world} GPU(s), no collective"},
+    }
+    if rank == 0:
+        bps = algorithmic_bytes_per_sim(A, S_dim, dbar)
+        ach = bps * G * S / (kernel_ms * 1e-3) / 1e9
+        fl = flops_per_sim(A, S_dim, H, L) * G * S / (kernel_ms * 1e-3) / 1e12
+        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "kernel": "k_search_fused<false>", "kernel_ms": kernel_ms,
+                           "bytes_per_sim": bps, "mean_path_len": dbar,
+                           "mfma_equiv": {"achieved": fl, "peak": F32_MATRIX_PEAK_TFLOPS,
+                                          "unit": "TFLOP/s", "frac": fl / F32_MATRIX_PEAK_TFLOPS,
+                                          "flops_per_sim": flops_per_sim(A, S_dim, H, L)},
+                           "note": "latency/occupancy-bound at this model size (SURVEY.md §8d)"}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(dims, w["blob"], S, eng.pbc)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
