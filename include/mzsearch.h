@@ -34,8 +34,10 @@ extern "C" {
 #define MZS_E_STATE (-3)    /* call out of order (e.g. search before set_weights) */
 
 /* search engines */
-#define MZS_ENGINE_FUSED 0    /* one persistent launch: wave per game, tree in LDS */
+#define MZS_ENGINE_FUSED 0    /* one launch per search: wave per game, tree in LDS; picks the
+                                 register-resident specialisation when the shape has one   */
 #define MZS_ENGINE_LOCKSTEP 1 /* select / inference / expand+backup kernels per simulation */
+#define MZS_ENGINE_FUSED_GENERIC 2 /* fused, always the runtime-shape kernel (A/B testing)  */
 
 typedef struct mzs_handle mzs_handle;
 

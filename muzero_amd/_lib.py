@@ -7,10 +7,12 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmzsearch.so")
+# MZS_LIB selects an alternative build of the same library (kernel A/B experiments)
+LIB_PATH = os.environ.get("MZS_LIB") or os.path.join(_HERE, "libmzsearch.so")
 
 ENGINE_FUSED = 0
 ENGINE_LOCKSTEP = 1
+ENGINE_FUSED_GENERIC = 2
 
 TREE_VISIT, TREE_VALUE_SUM, TREE_PRIOR, TREE_REWARD, TREE_CHILD_BASE = 0, 1, 2, 3, 4
 TREE_SIM_LEAF, TREE_MINMAX, TREE_HIDDEN, TREE_STATUS = 5, 6, 7, 8

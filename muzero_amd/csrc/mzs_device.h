@@ -81,31 +81,76 @@ __device__ __forceinline__ float readlane_f32(float v, int lane) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
 
-/* order-free reductions: result in every lane */
+/* ---- DPP cross-lane moves (row = 16 lanes): single VALU instructions, no LDS ---- */
+template <int kCtrl>
+__device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(
+        __builtin_amdgcn_update_dpp(0, __float_as_int(v), kCtrl, 0xF, 0xF, false));
+}
+constexpr int kDppQuadXor1 = 0xB1;      /* quad_perm [1,0,3,2] */
+constexpr int kDppQuadXor2 = 0x4E;      /* quad_perm [2,3,0,1] */
+constexpr int kDppRowHalfMirror = 0x141;
+constexpr int kDppRowMirror = 0x140;
+/* After these four in-row steps every lane of a 16-lane row holds the row's result.
+ * Contract "sum": adjacent-pair tree (a+b == b+a bitwise, so the mirrors stand in for
+ * the xor-4 / xor-8 exchanges). */
+__device__ __forceinline__ float row_tree_sum(float v) {
+    v = v + dpp_mov<kDppQuadXor1>(v);
+    v = v + dpp_mov<kDppQuadXor2>(v);
+    v = v + dpp_mov<kDppRowHalfMirror>(v);
+    v = v + dpp_mov<kDppRowMirror>(v);
+    return v;
+}
+
+__device__ __forceinline__ float row_max(float v) {
+    float t;
+    t = dpp_mov<kDppQuadXor1>(v);
+    v = t > v ? t : v;
+    t = dpp_mov<kDppQuadXor2>(v);
+    v = t > v ? t : v;
+    t = dpp_mov<kDppRowHalfMirror>(v);
+    v = t > v ? t : v;
+    t = dpp_mov<kDppRowMirror>(v);
+    v = t > v ? t : v;
+    return v;
+}
+
+/* uniform results of the two 32-lane halves (rows 0+1 and rows 2+3) */
+struct Halves {
+    float lo, hi;
+};
+
+__device__ __forceinline__ Halves halves_tree_sum(float v) {
+    v = row_tree_sum(v);
+    Halves h;
+    h.lo = readlane_f32(v, 0) + readlane_f32(v, 16);
+    h.hi = readlane_f32(v, 32) + readlane_f32(v, 48);
+    return h;
+}
+
+__device__ __forceinline__ Halves halves_max(float v) {
+    v = row_max(v);
+    const float r0 = readlane_f32(v, 0), r1 = readlane_f32(v, 16);
+    const float r2 = readlane_f32(v, 32), r3 = readlane_f32(v, 48);
+    Halves h;
+    h.lo = r1 > r0 ? r1 : r0;
+    h.hi = r3 > r2 ? r3 : r2;
+    return h;
+}
+
+/* order-free reductions over the wave: result uniform */
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        float t = __shfl_xor(v, o);
-        v = t > v ? t : v;
-    }
-    return v;
+    const Halves h = halves_max(v);
+    return h.hi > h.lo ? h.hi : h.lo;
 }
 
-__device__ __forceinline__ float wave_min(float v) {
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) {
-        float t = __shfl_xor(v, o);
-        v = t < v ? t : v;
-    }
-    return v;
-}
+__device__ __forceinline__ float wave_min(float v) { return -wave_max(-v); }
 
-/* contract "sum": adjacent-pair tree; lane i already holds v[2i] + v[2i+1].
- * a + b == b + a bitwise, so the xor butterfly leaves the same total in every lane. */
+/* contract "sum" over 64 lanes: adjacent-pair tree; lane i already holds
+ * v[2i] + v[2i+1]; the last level adds the two half sums. */
 __device__ __forceinline__ float wave_tree_sum(float v) {
-#pragma unroll
-    for (int o = 1; o < kWave; o <<= 1) v = v + __shfl_xor(v, o);
-    return v;
+    const Halves h = halves_tree_sum(v);
+    return h.lo + h.hi;
 }
 
 /* y = act(bias + W x): lane j owns neuron j (and j+64, ...); x is broadcast from LDS.
@@ -345,7 +390,8 @@ __device__ __forceinline__ void wave_expand(const SearchConst& c, const WaveLds&
 /* back_propagate_and_update_min_max_bound (mcts.py:203-209): path[0..depth], leaf last.
  * The value recurrence is a serial fp32 chain (product and sum rounded separately);
  * the per-node updates and the min/max of the new means are done one node per lane. */
-__device__ __forceinline__ void wave_backup(const SearchConst& c, SearchState& s, const WaveLds& L,
+template <typename State>
+__device__ __forceinline__ void wave_backup(const SearchConst& c, State& s, const WaveLds& L,
                                             int depth, float value, int lane) {
     float v = value;
     for (int top = depth; top >= 0; top -= kWave) {

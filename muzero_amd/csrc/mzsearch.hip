@@ -16,6 +16,7 @@
 
 #include "../../include/mzsearch.h"
 #include "mzs_device.h"
+#include "mzs_fast.h"
 
 using namespace mzs;
 
@@ -234,6 +235,221 @@ __global__ void __launch_bounds__(256) k_search_fused(const SearchParams p) {
 }
 
 /* ------------------------------------------------------------------------------
+ * Fast fused engine (mzs_fast.h): same search, weights in registers, hidden states in
+ * LDS, compile-time S_dim / A / H.  One wave serves games g, g + n_waves, ...
+ * ---------------------------------------------------------------------------- */
+__device__ __forceinline__ FastLds carve_fast(unsigned char* base, const FastLayout& l) {
+    FastLds L;
+    L.nodes = reinterpret_cast<Node*>(base);
+    L.cb = reinterpret_cast<unsigned short*>(base + l.off_cb);
+    L.path = reinterpret_cast<unsigned short*>(base + l.off_path);
+    L.meta = reinterpret_cast<unsigned*>(base + l.off_meta);
+    L.best = reinterpret_cast<unsigned short*>(base + l.off_best);
+    L.leafs = reinterpret_cast<unsigned short*>(base + l.off_leafs);
+    L.pbc = reinterpret_cast<double*>(base + l.off_pbc);
+    L.nwin = reinterpret_cast<double*>(base + l.off_nwin);
+    L.rootp = reinterpret_cast<double*>(base + l.off_rootp);
+    L.hid = reinterpret_cast<float*>(base + l.off_hid);
+    L.xa = reinterpret_cast<float*>(base + l.off_xa);
+    L.onehot = reinterpret_cast<float*>(base + l.off_onehot);
+    L.xo = reinterpret_cast<float*>(base + l.off_xo);
+    return L;
+}
+
+#ifdef MZS_DIAG
+/* diagnostic build only: per-phase cycle sums (s_memtime), never read by product code */
+__device__ unsigned long long g_diag[8];
+__device__ __forceinline__ unsigned long long diag_stamp() {
+    unsigned long long t;
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+    __builtin_amdgcn_sched_barrier(0);
+    return t;
+}
+#define DIAG_T(var) const unsigned long long var = diag_stamp()
+#define DIAG_ADD(i, a, b) dsum[i] += (b) - (a)
+#else
+#define DIAG_T(var)
+#define DIAG_ADD(i, a, b)
+#endif
+
+#ifndef MZS_FAST_WAVES
+#define MZS_FAST_WAVES 2
+#endif
+template <int SD, int NA, int H>
+__global__ void __launch_bounds__(256, MZS_FAST_WAVES) k_search_fast(const SearchParams p, const FastLayout fl) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    const int n_waves = gridDim.x * (blockDim.x >> 6);
+    /* block-shared weight copies first, then one slice per wave */
+    constexpr int kSharedFloats = 2 * ((SD + 3) / 4) * 64 * 4;
+    float* shared_w = reinterpret_cast<float*>(smem);
+    const FastLds L = carve_fast(smem + kSharedFloats * 4 + (size_t)wave * fl.bytes, fl);
+    const Model& m = p.m;
+    const int S = p.S;
+    const float* __restrict__ w = m.w;
+
+    FastWeights<SD, NA, H> W;
+    fast_load_weights<SD, NA, H>(m, W, shared_w, shared_w + kSharedFloats / 2, lane);
+    __syncthreads(); /* the only block-level barrier: every wave reaches it before its game loop */
+#pragma unroll
+    for (int a = 0; a < NA; ++a) L.onehot[a * 64 + lane] = w[m.d_in.w_off + (SD + a) * 64 + lane];
+
+    WaveLds T;  /* wave_backup only touches nodes / path */
+    T.nodes = L.nodes;
+    T.cb = L.cb;
+    T.path = L.path;
+    T.xh = T.xa = T.xb = T.ob = nullptr;
+    for (int i = lane; i < S + 2; i += kWave) L.pbc[i] = p.pbc[i];
+
+#ifdef MZS_DIAG
+    unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    for (int g = blockIdx.x * (blockDim.x >> 6) + wave; g < p.n_games; g += n_waves) {
+        DIAG_T(tg0);
+        SearchConst c;
+        c.A = NA;
+        c.S = S;
+        c.n_nodes = p.n_nodes;
+        c.g32 = p.g32;
+        c.pbc = p.pbc;
+        c.noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
+        c.noise_cap = p.noise ? p.noise_stride : 0;
+
+        FastState s;
+        s.mn = __builtin_inff();
+        s.mx = -__builtin_inff();
+        s.consumed = 0;
+        s.win_base = 0;
+        s.path_total = 0;
+        s.status = 0;
+        s.maxd = 1;
+
+        for (int n = lane; n < p.n_nodes; n += kWave) {
+            Node z;
+            z.visit = 0;
+            z.vsum = 0.0f;
+            z.prior = 0.0f;
+            z.reward = 0.0f;
+            L.nodes[n] = z;
+            L.cb[n] = 0;
+            L.best[n] = 0;
+            L.meta[n] = 1u << 16; /* root children: parent 0, depth 1 */
+        }
+        for (int k = lane; k < m.obs_dim; k += kWave) L.xo[k] = p.obs[(size_t)g * m.obs_dim + k];
+        if (S > 0) fast_noise_refill(c, s, L, lane);
+        wave_sync();
+
+        /* root: Representation_function.forward (weights streamed once from L2) */
+        {
+            float acc = w[m.r_in.b_off + lane];
+            for (int k = 0; k < m.obs_dim; ++k)
+                acc = mzs_fma(w[m.r_in.w_off + k * 64 + lane], L.xo[k], acc);
+            L.xa[lane] = mzs_elu(acc);
+            wave_sync();
+            acc = w[m.r_out.b_off + lane];
+#pragma unroll 8
+            for (int k = 0; k < H; ++k) acc = mzs_fma(w[m.r_out.w_off + k * 64 + lane], L.xa[k], acc);
+            const bool valid = lane < SD;
+            const float ninf = -__builtin_inff();
+            const float mx = halves_max(valid ? acc : ninf).lo;
+            const float mn = -halves_max(valid ? -acc : ninf).lo;
+            const float sc = mzs_bound_scale(mn, mx);
+            if (valid) L.hid[lane] = (acc - mn) / sc;
+            wave_sync();
+        }
+        float pr;
+        (void)fast_prediction<SD, NA, H>(W, L, L.hid, &pr, lane);
+        double rootp = 0.0;
+        if (lane < NA) {
+            L.nodes[1 + lane].prior = pr;
+            /* add_exploration_noise_at_the_root (mcts.py:134-145): f32 product widened, f64 sum */
+            if (p.train && S > 0)
+                rootp = (double)(pr * p.omf32) + p.dirichlet[(size_t)g * NA + lane] * p.frac;
+            else
+                rootp = (double)pr;
+            L.rootp[lane] = rootp;
+        }
+        if (lane == 0) L.cb[0] = 1;
+        wave_sync();
+
+        DIAG_T(tg1);
+        DIAG_ADD(0, tg0, tg1);
+        for (int sim = 0; sim < S; ++sim) {
+            int depth, action, pbase;
+            DIAG_T(t0);
+            const int leaf = fast_select<NA>(c, s, L, sim, &depth, &action, &pbase, lane);
+            DIAG_T(t1);
+            const int e_new = sim + 1, e_parent = (pbase - 1) / NA;
+            float* hn = L.hid + e_new * 32;
+            const float reward =
+                fast_dynamics<SD, NA, H>(W, L, L.hid + e_parent * 32, action, hn, lane);
+            DIAG_T(t2);
+            const float value = fast_prediction<SD, NA, H>(W, L, hn, &pr, lane);
+            DIAG_T(t3);
+            /* expand (mcts.py:186-200) */
+            const int cbase = 1 + e_new * NA;
+            if (lane < NA) {
+                L.nodes[cbase + lane].prior = pr;
+                L.meta[cbase + lane] = (unsigned)leaf | ((unsigned)(depth + 1) << 16);
+            }
+            if (lane == 0) {
+                L.nodes[leaf].reward = reward;
+                L.cb[leaf] = (unsigned short)cbase;
+                L.leafs[sim] = (unsigned short)leaf;
+            }
+            s.maxd = depth + 1 > s.maxd ? depth + 1 : s.maxd;
+            wave_sync();
+            wave_backup(c, s, T, depth, value, lane);
+            DIAG_T(t4);
+            DIAG_ADD(1, t0, t1);
+            DIAG_ADD(2, t1, t2);
+            DIAG_ADD(3, t2, t3);
+            DIAG_ADD(4, t3, t4);
+        }
+        DIAG_T(tg2);
+
+        /* tree + hidden states -> HBM structure of arrays; results (mcts.py:215-222) */
+        const size_t row = (size_t)g * p.t.stride;
+        for (int n = lane; n < p.n_nodes; n += kWave) {
+            const Node nd = L.nodes[n];
+            p.t.visit[row + n] = nd.visit;
+            p.t.vsum[row + n] = nd.vsum;
+            p.t.prior[row + n] = nd.prior;
+            p.t.reward[row + n] = nd.reward;
+            p.t.child_base[row + n] = L.cb[n];
+        }
+        for (int i = lane; i < S; i += kWave) p.t.sim_leaf[(size_t)g * p.t.max_sims + i] = L.leafs[i];
+        float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * p.t.hid_stride;
+        for (int i = lane; i < (S + 1) * 32; i += kWave) {
+            const int e = i >> 5, k = i & 31;
+            if (k < SD) hid_g[(size_t)e * p.t.hid_stride + k] = L.hid[i];
+        }
+        if (lane < NA) {
+            p.r.visits[(size_t)g * NA + lane] = L.nodes[1 + lane].visit;
+            p.r.root_prior[(size_t)g * NA + lane] = rootp;
+        }
+        if (lane == 0) {
+            const Node r = L.nodes[0];
+            p.r.root_value[g] = r.visit == 0 ? 0.0f : r.vsum / (float)r.visit;
+            p.r.consumed[g] = s.consumed;
+            p.r.path_len[g] = s.path_total;
+            p.t.minmax[2 * (size_t)g] = s.mn;
+            p.t.minmax[2 * (size_t)g + 1] = s.mx;
+            p.t.status[g] = s.status;
+        }
+        wave_sync();
+        DIAG_T(tg3);
+        DIAG_ADD(5, tg2, tg3);
+    }
+#ifdef MZS_DIAG
+    if (lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_diag[i], dsum[i]);
+#endif
+}
+
+/* ------------------------------------------------------------------------------
  * Standalone batched inference (wave per sample): the Muzero.*_inference wrappers
  * (muzero_model.py:828-905).
  * ---------------------------------------------------------------------------- */
@@ -294,6 +510,7 @@ struct mzs_handle {
     size_t w_floats = 0;
     bool have_weights = false;
     int n_nodes_max = 0;
+    int n_cus = 256;
     std::vector<void*> allocs;
 };
 
@@ -397,6 +614,49 @@ int launch(K kernel, const P& params, int units, const LdsLayout& lds, hipStream
     return MZS_OK;
 }
 
+FastLayout make_fast_layout(const Model& m, int n_nodes, int S) {
+    FastLayout l;
+    int off = round_up(n_nodes * (int)sizeof(Node), 16);
+    l.off_cb = off;
+    off += round_up(n_nodes * 2, 16);
+    l.off_path = off;
+    off += round_up((S + 2) * 2, 16);
+    l.off_meta = off;
+    off += round_up(n_nodes * 4, 16);
+    l.off_best = off;
+    off += round_up(n_nodes * 2, 16);
+    l.off_leafs = off;
+    off += round_up((S + 1) * 2, 16);
+    l.off_pbc = off;
+    off += round_up((S + 2) * 8, 16);
+    l.off_nwin = off;
+    off += kNoiseWin * 8;
+    l.off_rootp = off;
+    off += round_up(m.A * 8, 16);
+    l.off_hid = off;
+    off += (S + 1) * 32 * 4;
+    l.off_xa = off;
+    off += 64 * 4;
+    l.off_onehot = off;
+    off += m.A * 64 * 4;
+    l.off_xo = off;
+    off += 64 * 4;
+    l.bytes = round_up(off, 16);
+    return l;
+}
+
+/* the (S_dim, A, H) shapes the register-resident kernel is instantiated for */
+typedef void (*fast_kernel_t)(const SearchParams, const FastLayout);
+fast_kernel_t pick_fast_kernel(const mzs_dims& d) {
+    if (d.n_mid_layers != 0 || d.obs_dim > 64) return nullptr;
+    if (d.state_dim == 31 && d.n_actions == 2 && d.hidden_dim == 64) return k_search_fast<31, 2, 64>;
+    if (d.state_dim == 31 && d.n_actions == 4 && d.hidden_dim == 64) return k_search_fast<31, 4, 64>;
+    if (d.state_dim == 11 && d.n_actions == 2 && d.hidden_dim == 16) return k_search_fast<11, 2, 16>;
+    return nullptr;
+}
+
+int launch_fast(mzs_handle* h, fast_kernel_t kernel, const SearchParams& p, hipStream_t st);
+
 int check_search_args(mzs_handle* h, int n_games, int S, int train, const double* dirichlet,
                       const double* noise, int64_t stride) {
     if (!h) return fail(MZS_E_ARG, "null handle");
@@ -430,11 +690,40 @@ void fill_search_params(mzs_handle* h, SearchParams* p, int n_games, int S, int 
     p->noise_stride = stride;
 }
 
+int launch_fast(mzs_handle* h, fast_kernel_t kernel, const SearchParams& p, hipStream_t st) {
+    const FastLayout fl = make_fast_layout(p.m, p.n_nodes, p.S);
+    const int wpb = 4;
+    const size_t shared_w = 2 * (size_t)((p.m.Sd + 3) / 4) * 64 * 4 * sizeof(float);
+    const size_t shmem = shared_w + (size_t)wpb * fl.bytes;
+    if (shmem > (size_t)kMaxLdsPerBlock) return fail(MZS_E_ARG, "fast kernel LDS slice too large");
+    if (shmem > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    /* 2 waves per SIMD are resident (register-limited): 2 blocks of 4 waves per CU */
+    int blocks = (p.n_games + wpb - 1) / wpb;
+    const int resident = MZS_FAST_WAVES * h->n_cus;
+    if (blocks > resident) blocks = resident;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(wpb * kWave), shmem, st, p, fl);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
 }  // namespace
 
 extern "C" {
 
 const char* mzs_last_error(void) { return g_err.c_str(); }
+
+#ifdef MZS_DIAG
+/* diagnostic build only (not declared in mzsearch.h): read and clear the phase counters */
+int mzs_debug_counters(unsigned long long* out8) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipDeviceSynchronize() != hipSuccess) return MZS_E_HIP;
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_diag), sizeof z) != hipSuccess) return MZS_E_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z) != hipSuccess) return MZS_E_HIP;
+    return MZS_OK;
+}
+#endif
 const char* mzs_version(void) { return "mzsearch 0.1 (gfx950)"; }
 
 size_t mzs_weight_count(const mzs_dims* dims) {
@@ -454,13 +743,18 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     if (mzs_nodes_per_game(d.n_actions, cfg->max_simulations) > 65535)
         return fail(MZS_E_ARG, "tree exceeds 65535 nodes per game");
     if (cfg->max_simulations > 0 && !cfg->pbc_table) return fail(MZS_E_ARG, "pbc_table is null");
-    if (cfg->engine != MZS_ENGINE_FUSED)
+    if (cfg->engine != MZS_ENGINE_FUSED && cfg->engine != MZS_ENGINE_FUSED_GENERIC)
         return fail(MZS_E_ARG, "unknown engine");
     HIP_TRY(hipSetDevice(cfg->device));
     mzs_handle* h = new (std::nothrow) mzs_handle();
     if (!h) return fail(MZS_E_ARG, "out of host memory");
     h->cfg = *cfg;
     h->cfg.pbc_table = nullptr;
+    {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0)
+            h->n_cus = prop.multiProcessorCount;
+    }
     StoreBuilder sb;
     describe_model(d, &h->model, &sb);
     h->w_floats = sb.data.size();
@@ -564,6 +858,9 @@ int mzs_search(mzs_handle* h, int32_t n_games, int32_t S, int32_t train, const f
     SearchParams p;
     fill_search_params(h, &p, n_games, S, train, dirichlet_dev, noise_dev, noise_stride);
     p.obs = obs_dev;
+    fast_kernel_t fk = h->cfg.engine == MZS_ENGINE_FUSED ? pick_fast_kernel(h->cfg.dims) : nullptr;
+    if (fk && make_fast_layout(p.m, p.n_nodes, S).bytes * 4 <= kMaxLdsPerBlock / 2)
+        return launch_fast(h, fk, p, static_cast<hipStream_t>(stream));
     return launch(k_search_fused<false>, p, n_games, p.lds, static_cast<hipStream_t>(stream));
 }
 

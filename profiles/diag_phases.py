@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Diagnostic (not a benchmark): per-phase share of wave cycles in the fast fused kernel,
+from a -DMZS_DIAG build of the library (s_memtime stamps).  Usage on the GPU box:
+MZS_LIB=$PWD/muzero_amd/libmzsearch_diag.so python profiles/diag_phases.py"""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from muzero_amd import _lib, rng  # noqa: E402
+from muzero_amd.engine import SearchEngine  # noqa: E402
+
+w = np.load("tests/golden/weights_tag123.npz")
+dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L"))
+G, S = 4096, 50
+obs = np.random.RandomState(1000).uniform(-0.05, 0.05, size=(G, 4)).astype(np.float32)
+dirichlet, noise = rng.noise_streams(np.arange(G), 2, S, 0.25, True)
+eng = SearchEngine(dims, G, S, discount=0.997)
+eng.set_weights(w["blob"])
+lib = _lib.load()
+out = (C.c_ulonglong * 8)()
+for it in range(3):
+    eng.search(obs, dirichlet, noise, S, True)
+    eng.results_host()
+    lib.mzs_debug_counters(out)
+v = np.array(list(out), dtype=np.float64)
+names = ["root(init+repr+pred)", "select", "dynamics", "prediction", "expand+backup", "writeout", "-", "-"]
+tot = v.sum()
+for n, x in zip(names, v):
+    if x:
+        print(f"{n:22s} {x / (G * S):10.1f} cycles per sim   {100 * x / tot:5.1f} %")
+print(f"total {tot / (G * S):.1f} cycles per game-sim (stamps cost ~40 cycles each)")
