@@ -1,0 +1,273 @@
+"""`Muzero` — the reference's model wrapper (muzero_model.py:14) with the inference half
+running on the HIP kernels of libmzsearch.so.
+
+Kept from the reference (drop-in surface): the 19 constructor keyword
+arguments (muzero_model.py:16-35), the attributes self_play.py / muzero_cli.py read
+(`observation_dimension`, `action_dimension`, `is_RGB`, `action_dictionnary`,
+`k_hypothetical_steps`, `random_tag`, `store_loss`, `device`, `state_dimension`,
+`hidden_layer_dimension`, `number_of_hidden_layer`) and the three inference methods
+with their return types (muzero_model.py:828-905).
+
+Only `model_structure="mlp_model"` (neural_network_mlp_model.py) is implemented.
+Weights live in one packed fp32 blob (include/mzs_layout.h).
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import SearchEngine
+
+
+def _space_size(space):
+    """muzero_model.py:476-486 obs_space: Discrete -> 1, Box -> prod(shape), tuple -> sum."""
+    if isinstance(space, (int, np.integer)):
+        return int(space)
+    if isinstance(space, (tuple, list)):
+        return int(sum(_space_size(s) for s in space))
+    if hasattr(space, "shape") and space.shape not in (None, ()):
+        return int(np.prod(space.shape))
+    if hasattr(space, "n"):
+        return 1
+    raise TypeError(f"unsupported observation space {space!r}")
+
+
+def _action_dictionary(space, bin_method, bins):
+    """Gym_space_transform.design_observation_space (muzero_model.py:994-1051) for the
+    spaces the configs use: Discrete(n) -> [0..n-1]; Box -> `bins` samples per dimension,
+    cartesian product."""
+    import itertools
+    if isinstance(space, (int, np.integer)):
+        return list(range(int(space)))
+
+    def one(sp):
+        if hasattr(sp, "n"):
+            return [list(range(int(sp.n)))]
+        low = np.asarray(sp.low, np.float32).ravel()
+        high = np.asarray(sp.high, np.float32).ravel()
+        parts = []
+        for lo, hi in zip(low, high):
+            if "int" in str(sp.dtype):
+                parts.append(list(range(int(lo), int(hi))))
+            elif bin_method == "linear_bin":
+                parts.append(torch.linspace(float(lo), float(hi), steps=bins).tolist())
+            else:
+                parts.append(torch.distributions.uniform.Uniform(float(lo), float(hi)).sample([bins]).tolist())
+        return parts
+
+    parts = []
+    for sp in (space if isinstance(space, (tuple, list)) else [space]):
+        parts.extend(one(sp))
+    if len(parts) > 1:
+        return list(itertools.product(*parts))
+    return parts[0]
+
+
+def blob_layout(obs_dim, A, S_dim, H, L):
+    """(name, shape) of every tensor in the packed blob, in order (include/mzs_layout.h)."""
+    mid = lambda p: [(f"{p}_mid_w", (H, H)), (f"{p}_mid_b", (H,))] if L > 0 else []  # noqa: E731
+    return ([("r_in_w", (H, obs_dim)), ("r_in_b", (H,))] + mid("r") +
+            [("r_out_w", (S_dim, H)), ("r_out_b", (S_dim,))] +
+            [("d_in_w", (H, S_dim + A)), ("d_in_b", (H,))] + mid("d") +
+            [("d_rew_w", (S_dim, H)), ("d_rew_b", (S_dim,)), ("d_st_w", (S_dim, H)), ("d_st_b", (S_dim,))] +
+            [("p_in_w", (H, S_dim)), ("p_in_b", (H,))] + mid("p") +
+            [("p_pol_w", (A, H)), ("p_pol_b", (A,)), ("p_val_w", (S_dim, H)), ("p_val_b", (S_dim,))])
+
+
+def blob_from_state_dicts(repr_sd, dyn_sd, pred_sd, L):
+    """Pack `state_dict()`s of the reference's three MLP modules
+    (neural_network_mlp_model.py:7-128; shared trunk tensors appear once)."""
+    last = 2 * L + 2
+    g = lambda sd, k: np.asarray(sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else sd[k], np.float32)  # noqa: E731
+    parts = [g(repr_sd, "state_norm.0.weight"), g(repr_sd, "state_norm.0.bias")]
+    if L > 0:
+        parts += [g(repr_sd, "state_norm.2.weight"), g(repr_sd, "state_norm.2.bias")]
+    parts += [g(repr_sd, f"state_norm.{last}.weight"), g(repr_sd, f"state_norm.{last}.bias")]
+    parts += [g(dyn_sd, "reward.0.weight"), g(dyn_sd, "reward.0.bias")]
+    if L > 0:
+        parts += [g(dyn_sd, "reward.2.weight"), g(dyn_sd, "reward.2.bias")]
+    parts += [g(dyn_sd, f"reward.{last}.weight"), g(dyn_sd, f"reward.{last}.bias"),
+              g(dyn_sd, f"next_state_normalized.{last}.weight"), g(dyn_sd, f"next_state_normalized.{last}.bias")]
+    parts += [g(pred_sd, "policy.0.weight"), g(pred_sd, "policy.0.bias")]
+    if L > 0:
+        parts += [g(pred_sd, "policy.2.weight"), g(pred_sd, "policy.2.bias")]
+    parts += [g(pred_sd, f"policy.{last}.weight"), g(pred_sd, f"policy.{last}.bias"),
+              g(pred_sd, f"value.{last}.weight"), g(pred_sd, f"value.{last}.bias")]
+    return np.concatenate([p.ravel() for p in parts]).astype(np.float32)
+
+
+class Muzero:
+    def __init__(self, model_structure="mlp_model", observation_space_dimensions=None,
+                 action_space_dimensions=None, state_space_dimensions=9, k_hypothetical_steps=10,
+                 learning_rate=1e-3, optimizer="adam", lr_scheduler=None, loss_type="general",
+                 device="cuda", num_of_epoch=300, hidden_layer_dimensions=16,
+                 number_of_hidden_layer=1, load=False, type_format=torch.float32, use_amp=False,
+                 scaler_on=False, bin_method="uniform_bin", bin_decomposition_number=10):
+        self.reset(model_structure, observation_space_dimensions, action_space_dimensions,
+                   state_space_dimensions, k_hypothetical_steps, learning_rate, optimizer,
+                   lr_scheduler, loss_type, device, num_of_epoch, hidden_layer_dimensions,
+                   number_of_hidden_layer, load, type_format, use_amp, scaler_on, bin_method,
+                   bin_decomposition_number)
+
+    def reset(self, model_structure=None, observation_space_dimensions=None,
+              action_space_dimensions=None, state_space_dimensions=None, k_hypothetical_steps=None,
+              learning_rate=1e-3, optimizer="adam", lr_scheduler=None, loss_type="general",
+              device="cuda", num_of_epoch=300, hidden_layer_dimensions=64,
+              number_of_hidden_layer=1, load=False, type_format=torch.float32, use_amp=False,
+              scaler_on=False, bin_method="uniform_bin", bin_decomposition_number=10):
+        if model_structure not in (None, "mlp_model"):
+            raise NotImplementedError(f"model_structure={model_structure!r}: only 'mlp_model' has "
+                                      "MI355X kernels (SURVEY.md §8f lists the others as next)")
+        if type_format not in (torch.float32, None) or use_amp:
+            raise NotImplementedError("the search path computes in fp32 (bit-exact contract)")
+        self.model_structure = model_structure or "mlp_model"
+        self.state_dimension = state_space_dimensions
+        self.hidden_layer_dimension = hidden_layer_dimensions
+        self.number_of_hidden_layer = number_of_hidden_layer
+        self.k_hypothetical_steps = k_hypothetical_steps
+        self.loss_type, self.lr, self.opt, self.sch = loss_type, learning_rate, optimizer, lr_scheduler
+        self.epoch, self.count = num_of_epoch, 0
+        self.device = "cuda" if device in ("cpu", None) else device  # there is no CPU path
+        self.type_format = torch.float32
+        self.use_amp, self.scaler_on = False, False
+        self.random_tag = np.random.randint(0, 100000000)  # muzero_model.py:213 (global stream)
+        self.store_loss = []
+        self.bin_method, self.bin_decomposition_number = bin_method, bin_decomposition_number
+        self.is_RGB = False
+        self._engine = None
+        self._blob = None
+        self.weights_version = 0
+        if not load:
+            self.observation_dimension = _space_size(observation_space_dimensions)
+            self.action_dictionnary = _action_dictionary(action_space_dimensions, bin_method,
+                                                         bin_decomposition_number)
+            self.action_dimension = len(self.action_dictionnary)
+            self.initiate_model_weight()
+
+    # ------------------------------------------------------------------ weights
+    @property
+    def dims(self):
+        return (int(self.observation_dimension), int(self.action_dimension),
+                int(self.state_dimension), int(self.hidden_layer_dimension),
+                int(self.number_of_hidden_layer))
+
+    def initiate_model_weight(self):
+        """weights_init (neural_network_mlp_model.py:287-292): N(0, 1/137.035999) for every
+        Linear weight and bias, drawn from torch's global generator."""
+        n = sum(int(np.prod(s)) for _, s in blob_layout(*self.dims))
+        self.set_weights(torch.normal(0.0, 1 / 137.035999, size=(n,)).numpy())
+
+    def set_weights(self, blob):
+        blob = np.ascontiguousarray(blob, dtype=np.float32).ravel()
+        n = sum(int(np.prod(s)) for _, s in blob_layout(*self.dims))
+        if blob.size != n:
+            raise ValueError(f"weight blob has {blob.size} floats, expected {n}")
+        self._blob = blob
+        self.weights_version += 1
+        if self._engine is not None:
+            self._engine.set_weights(blob)
+
+    def weights_blob(self):
+        return self._blob
+
+    def named_weights(self):
+        out, p = {}, 0
+        for name, shape in blob_layout(*self.dims):
+            n = int(np.prod(shape))
+            out[name] = self._blob[p:p + n].reshape(shape)
+            p += n
+        return out
+
+    def load_reference_state_dicts(self, repr_sd, dyn_sd, pred_sd):
+        self.set_weights(blob_from_state_dicts(repr_sd, dyn_sd, pred_sd, self.number_of_hidden_layer))
+
+    # ---------------------------------------------------------------- inference
+    def _inference_engine(self):
+        if self._engine is None:
+            self._engine = SearchEngine(self.dims, max_games=1, max_simulations=0)
+            self._engine.set_weights(self._blob)
+        return self._engine
+
+    @staticmethod
+    def _as_batch(x):
+        if torch.is_tensor(x):
+            x = x.detach().to(torch.float32)
+        else:
+            x = torch.as_tensor(np.asarray(x, dtype=np.float32))
+        return x.reshape(1, -1) if x.dim() == 1 else x.reshape(x.shape[0], -1)
+
+    def representation_function_inference(self, state):
+        """muzero_model.py:828-845: observation -> cpu Tensor (B, state_dimension)."""
+        hid, _, _ = self._inference_engine().initial_inference(self._as_batch(state),
+                                                               want_prediction=False)
+        return hid.cpu()
+
+    def dynamics_function_inference(self, state_normalized, action):
+        """muzero_model.py:848-880: -> (np.float32 reward, cpu Tensor (1, state_dimension))."""
+        h = self._as_batch(state_normalized)
+        a = torch.as_tensor(action)
+        if a.dim() == 2:            # one-hot rows (muzero_model.py:497-498)
+            a = a.argmax(dim=1)
+        a = a.reshape(-1).to(torch.int32)
+        rew, nh, _, _ = self._inference_engine().recurrent_inference(h, a, want_prediction=False)
+        return rew.cpu().numpy()[0], nh.cpu()
+
+    def prediction_function_inference(self, state_normalized, reanalyze=False):
+        """muzero_model.py:883-905: -> (np.ndarray (B, A) softmax policy, np.float32 value),
+        or the value array when reanalyze=True."""
+        pol, val = self._inference_engine().prediction_inference(self._as_batch(state_normalized))
+        val = val.cpu().numpy()
+        return pol.cpu().numpy(), (val if reanalyze else val[0])
+
+    def train(self, batch):
+        raise NotImplementedError("the unroll-K training step is outside this round's scope "
+                                  "(SURVEY.md §8a T1-T7, secondary path)")
+
+    # -------------------------------------------------------------- checkpoints
+    def _init_variables(self):
+        return {"observation_space_dimensions": self.observation_dimension,
+                "action_space_dimensions": self.action_dimension,
+                "state_space_dimensions": self.state_dimension,
+                "hidden_layer_dimensions": self.hidden_layer_dimension,
+                "number_of_hidden_layer": self.number_of_hidden_layer,
+                "k_hypothetical_steps": self.k_hypothetical_steps, "learning_rate": self.lr,
+                "optimizer": self.opt, "loss_type": self.loss_type, "lr_scheduler": self.sch,
+                "num_of_epoch": self.epoch, "device": self.device, "random_tag": self.random_tag,
+                "action_map": self.action_dictionnary, "model_structure": self.model_structure,
+                "use_amp": self.use_amp}
+
+    def save_model(self, directory="model_checkpoint", tag=None, model_update_condition=None):
+        """Same JSON as muzero_model.py:923-941; the weights go to one `.npz` blob instead of
+        three pickled modules."""
+        if model_update_condition is not True:
+            return
+        os.makedirs(directory, exist_ok=True)
+        if tag:
+            self.random_tag = tag
+        np.savez(f"{directory}/{self.random_tag}_muzero_weights.npz", blob=self._blob)
+        with open(f"{directory}/{self.random_tag}_muzero_init_variables.json", "w") as f:
+            json.dump(self._init_variables(), f)
+
+    def load_model(self, model_directory="model_checkpoint", tag=0, observation_space_dimensions=None,
+                   type_format=torch.float32, device=None):
+        try:
+            with open(f"{model_directory}/{tag}_muzero_init_variables.json") as f:
+                iv = json.load(f)
+        except OSError:
+            raise Exception(f"file not found at : {model_directory}/{tag}_muzero_init_variables.json")
+        self.reset(model_structure=iv["model_structure"],
+                   state_space_dimensions=iv["state_space_dimensions"],
+                   k_hypothetical_steps=iv["k_hypothetical_steps"], optimizer=iv["optimizer"],
+                   lr_scheduler=iv["lr_scheduler"], learning_rate=iv["learning_rate"],
+                   loss_type=iv["loss_type"], device=device or iv["device"],
+                   num_of_epoch=iv["num_of_epoch"],
+                   hidden_layer_dimensions=iv["hidden_layer_dimensions"],
+                   number_of_hidden_layer=iv["number_of_hidden_layer"], load=True)
+        self.observation_dimension = iv["observation_space_dimensions"]
+        self.action_dictionnary = iv["action_map"]
+        self.action_dimension = len(self.action_dictionnary)
+        self.random_tag = tag if tag else iv["random_tag"]
+        path = f"{model_directory}/{iv['random_tag']}_muzero_weights.npz"
+        self.set_weights(np.load(path)["blob"])
