@@ -89,18 +89,12 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from muzero_amd import rng
+    from muzero_amd import rng, shard
     from muzero_amd.engine import SearchEngine
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    else:
-        torch.cuda.set_device(0)
-        local_rank = 0
+    rank, world = shard.init("nccl")          # nccl == RCCL on ROCm; no-op for one rank
+    local_rank = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
     w = np.load(os.path.join(ROOT, "tests", "golden", f"weights_{args.weights}.npz"))
@@ -109,8 +103,8 @@ def main():
     G, S = args.games, args.sims
 
     # synthetic inputs of the BASELINE shape
-    obs = np.random.RandomState(1000 + rank).uniform(-0.05, 0.05, size=(G, obs_dim)).astype(np.float32)
-    dirichlet, noise = rng.noise_streams(rank * G + np.arange(G), A, S, 0.25, True)
+    obs, seeds = shard.shard_inputs(rank, G, obs_dim)
+    dirichlet, noise = rng.noise_streams(seeds, A, S, 0.25, True)
     eng = SearchEngine(dims, G, S, discount=0.997, device=local_rank)
     eng.set_weights(w["blob"])
     obs_d = torch.as_tensor(obs).to(dev)
@@ -146,11 +140,7 @@ def main():
     for i in range(args.steps):
         res = step(i)
     fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = shard.max_over_ranks(time.perf_counter() - t0, dev)
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
     path_len = res["path_len"].cpu().numpy()
