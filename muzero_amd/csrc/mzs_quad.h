@@ -1,0 +1,474 @@
+/*
+ * mzs_quad.h — four games per wavefront, dense layers on v_mfma_f32_4x4x1_16b_f32.
+ *
+ * The fused search for the small MLP shapes of the benchmark configs (L = 0, H <= 64,
+ * S_dim <= 32, A <= 4; compile-time SD / NA / H).  Same arithmetic as the generic kernel
+ * (include/mzs_numeric.h), bit for bit: an f32 MFMA is a k-ordered fmaf chain.
+ *
+ * Lane roles.  lane l: game c = l & 3, block b = l >> 2.
+ *   MFMA (16 blocks of 4x4, K = 1 per instruction):  D[r][lane (b, c)] += A[lane 4b + r] * B
+ *     A operand: weights, lane 4b + r holds W[neuron n(b, r)][k]             (registers, all search long)
+ *     B operand: inputs, lane 16g + 4bb + c holds x[game c][k = 16g + q] in register q;
+ *                BLGP = 4 + g broadcasts lane group g to all sixteen blocks
+ *     D: lane (b, c) register r = pre-activation of neuron n(b, r) for game c
+ *   n(b, r) = 32 * half + 4 * eb + r, half = b >> 3, eb = b1 + 2 b0 + 4 b2 (bits of b): with
+ *   this numbering the adjacent-pair sum tree of contract "sum" is: four registers in the lane,
+ *   row_ror:8, row_ror:4, then the neighbouring row (v_permlane16_swap) — the two 32-lane
+ *   halves reduce separately and hold the two heads of a net (reward | next state,
+ *   policy | value).
+ *   Tree work: lanes with equal (c, a = b % A') score child a of game c's current node
+ *   (A' = A rounded up to a power of two); b is the path level in backup.
+ *
+ * Reference code restated (file:line in /root/reference): as mzs_device.h.
+ */
+#ifndef MZS_QUAD_H
+#define MZS_QUAD_H
+
+#include "mzs_device.h"
+
+namespace mzs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kDppRowRor4 = 0x124;
+constexpr int kDppRowRor8 = 0x128;
+
+struct QuadLane {
+    int lane, c, b, grp, half, eb, n0; /* n0 = first of the four neurons of this lane's D registers */
+};
+
+__device__ __forceinline__ QuadLane quad_lane() {
+    QuadLane q;
+    q.lane = lane_id();
+    q.c = q.lane & 3;
+    q.b = q.lane >> 2;
+    q.grp = q.lane >> 4;
+    q.half = q.lane >> 5;
+    q.eb = ((q.b >> 1) & 1) | ((q.b & 1) << 1) | (q.b & 4);
+    q.n0 = 32 * q.half + 4 * q.eb;
+    return q;
+}
+
+/* neuron whose weights lane l holds as the A operand */
+__device__ __forceinline__ int quad_neuron_of_lane(int l) {
+    const int b = l >> 2;
+    const int eb = ((b >> 1) & 1) | ((b & 1) << 1) | (b & 4);
+    return 32 * (l >> 5) + 4 * eb + (l & 3);
+}
+
+/* {value in the even row, value in the odd row} of this lane's row pair / {low half, high half} */
+__device__ __forceinline__ void rows_pair(float v, float& x, float& y) {
+    const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    x = __uint_as_float(r[0]);
+    y = __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ void halves_pair(float v, float& lo, float& hi) {
+    const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    lo = __uint_as_float(r[0]);
+    hi = __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ float low_half(float v) {
+    float lo, hi;
+    halves_pair(v, lo, hi);
+    return lo;
+}
+
+__device__ __forceinline__ float high_half(float v) {
+    float lo, hi;
+    halves_pair(v, lo, hi);
+    return hi;
+}
+
+__device__ __forceinline__ float fmax_sel(float a, float b) { return b > a ? b : a; }
+
+/* reductions over the 8 blocks of this lane's half, per game (result in every lane of the half) */
+__device__ __forceinline__ float half_sum(float v) {
+    v = v + dpp_mov<kDppRowRor8>(v);
+    v = v + dpp_mov<kDppRowRor4>(v);
+    float x, y;
+    rows_pair(v, x, y);
+    return x + y;
+}
+
+__device__ __forceinline__ float half_max(float v) {
+    v = fmax_sel(v, dpp_mov<kDppRowRor8>(v));
+    v = fmax_sel(v, dpp_mov<kDppRowRor4>(v));
+    float x, y;
+    rows_pair(v, x, y);
+    return fmax_sel(x, y);
+}
+
+/* over all 16 lanes of the game */
+__device__ __forceinline__ float game_max(float v) {
+    v = half_max(v);
+    float lo, hi;
+    halves_pair(v, lo, hi);
+    return fmax_sel(lo, hi);
+}
+
+__device__ __forceinline__ float sum4(const f32x4 v) { return (v[0] + v[1]) + (v[2] + v[3]); }
+__device__ __forceinline__ float max4(const f32x4 v) {
+    return fmax_sel(fmax_sel(v[0], v[1]), fmax_sel(v[2], v[3]));
+}
+
+/* one fma-chain step for k = K0 .. K-1: acc[r] = fma(w[k], x[k], acc[r]) for the four games */
+template <int K, int k = 0>
+__device__ __forceinline__ void quad_chain(const float* w, const float* x, f32x4& acc) {
+    if constexpr (k < K) {
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[k], x[k & 15], acc, 0, 0, 4 + (k >> 4));
+        quad_chain<K, k + 1>(w, x, acc);
+    }
+}
+
+/* B-operand registers: x[q] = row[16 * g + q] */
+__device__ __forceinline__ void quad_load_x(const float* row, int g, float (&x)[16]) {
+    const float4* p = reinterpret_cast<const float4*>(row + 16 * g);
+    const float4 v0 = p[0], v1 = p[1], v2 = p[2], v3 = p[3];
+    x[0] = v0.x, x[1] = v0.y, x[2] = v0.z, x[3] = v0.w;
+    x[4] = v1.x, x[5] = v1.y, x[6] = v1.z, x[7] = v1.w;
+    x[8] = v2.x, x[9] = v2.y, x[10] = v2.z, x[11] = v2.w;
+    x[12] = v3.x, x[13] = v3.y, x[14] = v3.z, x[15] = v3.w;
+}
+
+template <int SD, int NA, int H>
+struct QuadWeights {
+    float d_in[SD], d_h[H], p_in[SD], p_h[H];
+    f32x4 b_d_in, b_d_h, b_p_in, b_p_h;
+};
+
+/* per-wave LDS */
+struct QuadLds {
+    float* trunk;            /* [4][64] trunk activations, game-major                      */
+    double* nwin;            /* [64] tie-break draws of the next descent: [level][a][game]  */
+    const float* onehot;     /* block-shared [NA][64] action columns of the dynamics input  */
+    const double* pbc;       /* block-shared [S+2] sqrt(n) * pb_c(n)                        */
+    /* this lane's game */
+    Node* nodes;
+    unsigned short* cb;
+    uint2* path;             /* [S+2] {node, reward bits}                                   */
+    float* hid;              /* [S+1][32]                                                   */
+    unsigned short* leafs;   /* [S]                                                         */
+};
+
+struct QuadLayout {
+    int off_onehot, shared_bytes;              /* block-shared part: pbc at 0           */
+    int off_nwin, off_games, wave_bytes;       /* per wave: trunk at 0                  */
+    int g_cb, g_path, g_hid, g_leafs, g_bytes; /* per game: nodes at 0                  */
+};
+
+template <int SD, int NA, int H>
+__device__ __forceinline__ void quad_load_weights(const Model& m, QuadWeights<SD, NA, H>& W,
+                                                  const QuadLane& q) {
+    const float* __restrict__ w = m.w;
+    const int n = quad_neuron_of_lane(q.lane);
+#pragma unroll
+    for (int k = 0; k < SD; ++k) W.d_in[k] = w[m.d_in.w_off + k * 64 + n];
+#pragma unroll
+    for (int k = 0; k < H; ++k) W.d_h[k] = w[m.d_heads.w_off + k * 64 + n];
+#pragma unroll
+    for (int k = 0; k < SD; ++k) W.p_in[k] = w[m.p_in.w_off + k * 64 + n];
+#pragma unroll
+    for (int k = 0; k < H; ++k) W.p_h[k] = w[m.p_heads.w_off + k * 64 + n];
+    const auto b4 = [&](int off) {
+        const float4 v = *reinterpret_cast<const float4*>(w + off + q.n0);
+        return f32x4{v.x, v.y, v.z, v.w};
+    };
+    W.b_d_in = b4(m.d_in.b_off);
+    W.b_d_h = b4(m.d_heads.b_off);
+    W.b_p_in = b4(m.p_in.b_off);
+    W.b_p_h = b4(m.p_heads.b_off);
+}
+
+__device__ __forceinline__ f32x4 elu4(const f32x4 v) {
+    return f32x4{mzs_elu(v[0]), mzs_elu(v[1]), mzs_elu(v[2]), mzs_elu(v[3])};
+}
+
+__device__ __forceinline__ void store4(float* p, const f32x4 v) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+
+/* ELU(trunk) of the four games -> LDS, back as the B operand of the head layer */
+__device__ __forceinline__ void quad_trunk_to_x(const QuadLds& L, const QuadLane& q, const f32x4 acc,
+                                                float (&x)[16]) {
+    store4(L.trunk + q.c * 64 + q.n0, elu4(acc));
+    wave_sync();
+    quad_load_x(L.trunk + q.c * 64, q.grp, x);
+    wave_sync();
+}
+
+/* softmax over the valid logits of this lane's half (contract exp + sum) */
+__device__ __forceinline__ f32x4 quad_softmax(const f32x4 o, const bool (&valid)[4]) {
+    const float ninf = -__builtin_inff();
+    const float m = half_max(max4(f32x4{valid[0] ? o[0] : ninf, valid[1] ? o[1] : ninf,
+                                        valid[2] ? o[2] : ninf, valid[3] ? o[3] : ninf}));
+    f32x4 e;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) e[r] = valid[r] ? mzs_expf(o[r] - m) : 0.0f;
+    const float Z = half_sum(sum4(e));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) e[r] = e[r] / Z;
+    return e;
+}
+
+/* expectation over the support i - SD/2 of probabilities p, then the inverse value transform
+ * (muzero_model.py:580-586) */
+template <int SD>
+__device__ __forceinline__ float quad_support_scalar(const f32x4 p, const bool (&valid)[4], int i0) {
+    f32x4 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = valid[r] ? (float)(i0 + r - SD / 2) * p[r] : 0.0f;
+    return mzs_inverse_value_transform(half_sum(sum4(t)));
+}
+
+/* scale_to_bound_action (neural_network_mlp_model.py:135-143) of this lane's half */
+__device__ __forceinline__ f32x4 quad_scale_to_bound(const f32x4 o, const bool (&valid)[4]) {
+    const float ninf = -__builtin_inff();
+    const float mx = half_max(max4(f32x4{valid[0] ? o[0] : ninf, valid[1] ? o[1] : ninf,
+                                         valid[2] ? o[2] : ninf, valid[3] ? o[3] : ninf}));
+    const float mn = -half_max(max4(f32x4{valid[0] ? -o[0] : ninf, valid[1] ? -o[1] : ninf,
+                                          valid[2] ? -o[2] : ninf, valid[3] ? -o[3] : ninf}));
+    const float sc = mzs_bound_scale(mn, mx);
+    f32x4 y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = valid[r] ? (o[r] - mn) / sc : 0.0f;
+    return y;
+}
+
+/* Prediction_function on the hidden-state row `h` of each game (LDS): policy logits in the
+ * low half (block eb = 0 holds actions 0..3: lanes 0..3), value logits in the high half; the two
+ * softmaxes run in the same instructions.  Returns the value in the high half's lanes. */
+template <int SD, int NA, int H>
+__device__ __forceinline__ float quad_prediction(const QuadWeights<SD, NA, H>& W, const QuadLds& L,
+                                                 const QuadLane& q, const float* h, f32x4* prior) {
+    float x[16];
+    quad_load_x(h, q.grp & 1, x);
+    f32x4 acc = W.b_p_in;
+    quad_chain<SD>(W.p_in, x, acc);
+    quad_trunk_to_x(L, q, acc, x);
+    acc = W.b_p_h;
+    quad_chain<H>(W.p_h, x, acc);
+    const int i0 = 4 * q.eb, lim = q.half ? SD : NA;
+    const bool valid[4] = {i0 < lim, i0 + 1 < lim, i0 + 2 < lim, i0 + 3 < lim};
+    const f32x4 p = quad_softmax(acc, valid);
+    *prior = p;
+    const bool vv[4] = {valid[0] && q.half, valid[1] && q.half, valid[2] && q.half, valid[3] && q.half};
+    return quad_support_scalar<SD>(p, vv, i0);
+}
+
+/* Dynamics_function on row `h` + action: reward logits in the low half, next-state
+ * pre-activations in the high half; the new hidden state goes to row `hn` (LDS).  Returns the
+ * reward in the low half's lanes. */
+template <int SD, int NA, int H>
+__device__ __forceinline__ float quad_dynamics(const QuadWeights<SD, NA, H>& W, const QuadLds& L,
+                                               const QuadLane& q, const float* h, int action, float* hn) {
+    float x[16];
+    quad_load_x(h, q.grp & 1, x);
+    const float4 oh = *reinterpret_cast<const float4*>(L.onehot + action * 64 + q.n0);
+    f32x4 acc = W.b_d_in;
+    quad_chain<SD>(W.d_in, x, acc);
+    /* one-hot action column (muzero_model.py:502): fma(1, w, acc) == acc + w */
+    acc = f32x4{acc[0] + oh.x, acc[1] + oh.y, acc[2] + oh.z, acc[3] + oh.w};
+    quad_trunk_to_x(L, q, acc, x);
+    acc = W.b_d_h;
+    quad_chain<H>(W.d_h, x, acc);
+    const int i0 = 4 * q.eb;
+    const bool valid[4] = {i0 < SD, i0 + 1 < SD, i0 + 2 < SD, i0 + 3 < SD};
+    /* reward head */
+    const f32x4 p = quad_softmax(acc, valid);
+    const float reward = quad_support_scalar<SD>(p, valid, i0);
+    /* next state */
+    const f32x4 y = quad_scale_to_bound(acc, valid);
+    if (q.half) store4(hn + i0, y);
+    wave_sync();
+    return reward;
+}
+
+/* Representation_function on the observations staged in L.trunk ([game][64]); weights streamed
+ * from L2 (once per search).  Hidden state to row `h0` of each game. */
+template <int SD, int NA, int H>
+__device__ __forceinline__ void quad_representation(const Model& m, const QuadLds& L, const QuadLane& q,
+                                                    float* h0) {
+    const float* __restrict__ w = m.w;
+    const int n = quad_neuron_of_lane(q.lane);
+    const auto b4 = [&](int off) {
+        const float4 v = *reinterpret_cast<const float4*>(w + off + q.n0);
+        return f32x4{v.x, v.y, v.z, v.w};
+    };
+    f32x4 acc = b4(m.r_in.b_off);
+    for (int k = 0; k < m.obs_dim; ++k)
+        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[m.r_in.w_off + k * 64 + n], L.trunk[q.c * 64 + k], acc,
+                                                 0, 0, 0);
+    wave_sync();
+    float x[16];
+    quad_trunk_to_x(L, q, acc, x);
+    acc = b4(m.r_out.b_off);
+    float wk[H];
+#pragma unroll
+    for (int k = 0; k < H; ++k) wk[k] = w[m.r_out.w_off + k * 64 + n];
+    quad_chain<H>(wk, x, acc);
+    const int i0 = 4 * q.eb;
+    const bool valid[4] = {i0 < SD, i0 + 1 < SD, i0 + 2 < SD, i0 + 3 < SD};
+    const f32x4 y = quad_scale_to_bound(acc, valid);
+    if (!q.half) store4(h0 + i0, y);
+    wave_sync();
+}
+
+/* ------------------------------------------------------------------ search */
+
+struct QuadState {
+    float mn, mx;       /* MinMaxStats of this lane's game        */
+    double rootp;       /* root-child prior of (game, a) after noise */
+    int consumed;       /* tie-break draws consumed               */
+    int path_total;
+    int status;
+};
+
+template <int kCtrl>
+__device__ __forceinline__ double quad_dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xF, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
+/* max over (score, action) tuples with the chosen child's record riding along */
+template <int kCtrl>
+__device__ __forceinline__ void quad_argmax_step(double& bs, int& ba, unsigned& pay, float& rew) {
+    const double os = quad_dpp_f64<kCtrl>(bs);
+    const int oa = __builtin_amdgcn_update_dpp(0, ba, kCtrl, 0xF, 0xF, false);
+    const unsigned op = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pay, kCtrl, 0xF, 0xF, false);
+    const float orw = dpp_mov<kCtrl>(rew);
+    /* ties -> larger action (mcts.py:167) */
+    const bool take = (os > bs) || (os == bs && oa > ba);
+    bs = take ? os : bs;
+    ba = take ? oa : ba;
+    pay = take ? op : pay;
+    rew = take ? orw : rew;
+}
+
+/* Descent of the four games at once, one tree level per iteration (mcts.py:155-177).
+ * Lane (c, a) scores child a of game c's current node; games that reached a leaf idle. */
+template <int NA>
+struct QuadSelect {
+    int leaf, depth, action, pbase;
+};
+
+template <int NA>
+__device__ __forceinline__ QuadSelect<NA> quad_select(const QuadLds& L, QuadState& s, const QuadLane& q,
+                                                      const double* __restrict__ noise, int noise_cap,
+                                                      float g32, int sim) {
+    constexpr int NAL = NA <= 2 ? 2 : 4; /* lanes per sibling group */
+    constexpr int kWin = 16 / NAL;       /* levels held by the LDS window */
+    const int a = q.b & (NAL - 1);
+    QuadSelect<NA> r;
+    r.leaf = 0, r.depth = 0, r.action = 0, r.pbase = 0;
+    int cbn = 1;     /* the root is expanded: its children start at node 1 */
+    int pv = sim;    /* root visit count = completed simulations */
+    for (int t = 0;; ++t) {
+        const bool active = cbn != 0;
+        if (__builtin_amdgcn_ballot_w64(active) == 0) break;
+        const int child = (active ? cbn : 1) + (a < NA ? a : 0);
+        const Node ch = L.nodes[child];
+        const int ccb = L.cb[child];
+        const double tn = L.pbc[pv];
+        double u;
+        if (t < kWin) {
+            u = L.nwin[(t * NAL + a) * 4 + q.c];
+        } else {
+            const int ni = s.consumed + t * NA + a;
+            u = (noise && a < NA && ni < noise_cap) ? noise[ni] : 0.0;
+        }
+        /* ucb_score (mcts.py:155-163) */
+        const double pd = t == 0 ? s.rootp : (double)ch.prior;
+        const double ps = (tn * pd) / (double)(ch.visit + 1);
+        double vs = 0.0;
+        if (ch.visit > 0) {
+            const float qv = ch.vsum / (float)ch.visit;
+            float x = g32 * qv;
+            x = ch.reward + x;
+            if (s.mx > s.mn) x = (x - s.mn) / (s.mx - s.mn);
+            vs = (double)x;
+        }
+        double bs = (ps + vs) + u;
+        if (NA < NAL && a >= NA) bs = -__builtin_inf();
+        int ba = a;
+        unsigned pay = (unsigned)ccb | ((unsigned)ch.visit << 16);
+        float rew = ch.reward;
+        if (NAL == 4) quad_argmax_step<kDppRowRor8>(bs, ba, pay, rew);
+        quad_argmax_step<kDppRowRor4>(bs, ba, pay, rew);
+        if (active) {
+            r.pbase = cbn;
+            r.action = ba;
+            r.leaf = cbn + ba;
+            r.depth += 1;
+            pv = (int)(pay >> 16);
+            cbn = (int)(pay & 0xffffu);
+            if (q.b == 0) L.path[r.depth] = make_uint2((unsigned)r.leaf, __float_as_uint(rew));
+        }
+    }
+    s.consumed += NA * r.depth;
+    if (s.consumed > noise_cap) s.status = 1;
+    s.path_total += r.depth;
+    wave_sync();
+    return r;
+}
+
+/* draws of the next descent: lane (c, a, level j = b / NAL) fetches draw consumed + j * NA + a */
+template <int NA>
+__device__ __forceinline__ double quad_noise_prefetch(const QuadState& s, const QuadLane& q,
+                                                      const double* __restrict__ noise, int noise_cap) {
+    constexpr int NAL = NA <= 2 ? 2 : 4;
+    const int a = q.b & (NAL - 1), j = q.b / NAL;
+    const int ni = s.consumed + j * NA + a;
+    return (noise && a < NA && ni < noise_cap) ? noise[ni] : 0.0;
+}
+
+/* back_propagate_and_update_min_max_bound (mcts.py:203-209) for the four games: the value
+ * recurrence is a serial fp32 chain per game (product and sum rounded separately); the node
+ * updates of up to kChunk path levels run one per lane. */
+__device__ __forceinline__ void quad_backup(const QuadLds& L, QuadState& s, const QuadLane& q, int depth,
+                                            float value, float g32) {
+    constexpr int kChunk = 8;
+    int dmax = depth;
+    dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, kDppQuadXor1, 0xF, 0xF, false));
+    dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, kDppQuadXor2, 0xF, 0xF, false));
+    dmax = __builtin_amdgcn_readfirstlane(dmax);
+    const int slot = q.b & (kChunk - 1);
+    const float pinf = __builtin_inff();
+    float v = value;
+    for (int hi = dmax; hi >= 0; hi -= kChunk) {
+        float rw[kChunk];
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) rw[k] = __uint_as_float(L.path[hi - k > 0 ? hi - k : 0].y);
+        const int lvl = hi - slot;
+        const bool mine = q.b < kChunk && lvl >= 0 && lvl <= depth;
+        const int pn = (int)L.path[mine ? lvl : 0].x;
+        const int2 rec = *reinterpret_cast<const int2*>(&L.nodes[pn]);
+        float myv = 0.0f;
+#pragma unroll
+        for (int k = 0; k < kChunk; ++k) {
+            const bool on = hi - k >= 0 && hi - k <= depth;
+            myv = (on && slot == k) ? v : myv;
+            const float gv = g32 * v;
+            const float nv = rw[k] + gv;
+            v = on ? nv : v;
+        }
+        float qv = 0.0f;
+        if (mine) {
+            const float vsum = __int_as_float(rec.y) + myv;
+            const int visit = rec.x + 1;
+            qv = vsum / (float)visit;
+            *reinterpret_cast<int2*>(&L.nodes[pn]) = make_int2(visit, __float_as_int(vsum));
+        }
+        const float qmx = game_max(mine ? qv : -pinf);
+        const float qmn = -game_max(mine ? -qv : -pinf);
+        s.mx = qmx > s.mx ? qmx : s.mx;
+        s.mn = qmn < s.mn ? qmn : s.mn;
+        wave_sync();
+    }
+}
+
+}  // namespace mzs
+#endif

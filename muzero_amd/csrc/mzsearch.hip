@@ -16,7 +16,7 @@
 
 #include "../../include/mzsearch.h"
 #include "mzs_device.h"
-#include "mzs_fast.h"
+#include "mzs_quad.h"
 
 using namespace mzs;
 
@@ -235,27 +235,10 @@ __global__ void __launch_bounds__(256) k_search_fused(const SearchParams p) {
 }
 
 /* ------------------------------------------------------------------------------
- * Fast fused engine (mzs_fast.h): same search, weights in registers, hidden states in
- * LDS, compile-time S_dim / A / H.  One wave serves games g, g + n_waves, ...
+ * Quad fused engine (mzs_quad.h): four games per wavefront, dense layers on
+ * v_mfma_f32_4x4x1_16b_f32 with the weights in registers, trees and hidden states in LDS,
+ * compile-time S_dim / A / H.  One block = up to four waves = sixteen games.
  * ---------------------------------------------------------------------------- */
-__device__ __forceinline__ FastLds carve_fast(unsigned char* base, const FastLayout& l) {
-    FastLds L;
-    L.nodes = reinterpret_cast<Node*>(base);
-    L.cb = reinterpret_cast<unsigned short*>(base + l.off_cb);
-    L.path = reinterpret_cast<unsigned short*>(base + l.off_path);
-    L.meta = reinterpret_cast<unsigned*>(base + l.off_meta);
-    L.best = reinterpret_cast<unsigned short*>(base + l.off_best);
-    L.leafs = reinterpret_cast<unsigned short*>(base + l.off_leafs);
-    L.pbc = reinterpret_cast<double*>(base + l.off_pbc);
-    L.nwin = reinterpret_cast<double*>(base + l.off_nwin);
-    L.rootp = reinterpret_cast<double*>(base + l.off_rootp);
-    L.hid = reinterpret_cast<float*>(base + l.off_hid);
-    L.xa = reinterpret_cast<float*>(base + l.off_xa);
-    L.onehot = reinterpret_cast<float*>(base + l.off_onehot);
-    L.xo = reinterpret_cast<float*>(base + l.off_xo);
-    return L;
-}
-
 #ifdef MZS_DIAG
 /* diagnostic build only: per-phase cycle sums (s_memtime), never read by product code */
 __device__ unsigned long long g_diag[8];
@@ -273,146 +256,146 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 #define DIAG_ADD(i, a, b)
 #endif
 
-#ifndef MZS_FAST_WAVES
-#define MZS_FAST_WAVES 2
-#endif
-template <int SD, int NA, int H>
-__global__ void __launch_bounds__(256, MZS_FAST_WAVES) k_search_fast(const SearchParams p, const FastLayout fl) {
+template <int SD, int NA, int H, bool kInjected>
+__global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, const QuadLayout ql) {
     extern __shared__ __align__(16) unsigned char smem[];
-    const int lane = lane_id();
+    const QuadLane q = quad_lane();
     const int wave = threadIdx.x >> 6;
-    const int n_waves = gridDim.x * (blockDim.x >> 6);
-    /* block-shared weight copies first, then one slice per wave */
-    constexpr int kSharedFloats = 2 * ((SD + 3) / 4) * 64 * 4;
-    float* shared_w = reinterpret_cast<float*>(smem);
-    const FastLds L = carve_fast(smem + kSharedFloats * 4 + (size_t)wave * fl.bytes, fl);
     const Model& m = p.m;
     const int S = p.S;
-    const float* __restrict__ w = m.w;
 
-    FastWeights<SD, NA, H> W;
-    fast_load_weights<SD, NA, H>(m, W, shared_w, shared_w + kSharedFloats / 2, lane);
-    __syncthreads(); /* the only block-level barrier: every wave reaches it before its game loop */
+    /* block-shared tables, then the only block-level barrier */
+    double* pbc_s = reinterpret_cast<double*>(smem);
+    float* onehot_s = reinterpret_cast<float*>(smem + ql.off_onehot);
+    for (int i = threadIdx.x; i < S + 2; i += blockDim.x) pbc_s[i] = p.pbc[i];
+    QuadWeights<SD, NA, H> W;
+    if (!kInjected) {
+        for (int i = threadIdx.x; i < NA * 64; i += blockDim.x)
+            onehot_s[i] = m.w[m.d_in.w_off + (SD + (i >> 6)) * 64 + (i & 63)];
+        quad_load_weights<SD, NA, H>(m, W, q);
+    }
+    __syncthreads();
+
+    const int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 4;
+    if (g0 >= p.n_games) return;
+    const bool live = g0 + q.c < p.n_games;          /* dead slots replay the last game, write nothing */
+    const int g = live ? g0 + q.c : p.n_games - 1;
+
+    unsigned char* wbase = smem + ql.shared_bytes + (size_t)wave * ql.wave_bytes;
+    unsigned char* gbase = wbase + ql.off_games + (size_t)q.c * ql.g_bytes;
+    QuadLds L;
+    L.trunk = reinterpret_cast<float*>(wbase);
+    L.nwin = reinterpret_cast<double*>(wbase + ql.off_nwin);
+    L.onehot = onehot_s;
+    L.pbc = pbc_s;
+    L.nodes = reinterpret_cast<Node*>(gbase);
+    L.cb = reinterpret_cast<unsigned short*>(gbase + ql.g_cb);
+    L.path = reinterpret_cast<uint2*>(gbase + ql.g_path);
+    L.hid = reinterpret_cast<float*>(gbase + ql.g_hid);
+    L.leafs = reinterpret_cast<unsigned short*>(gbase + ql.g_leafs);
+
+    const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
+    const int noise_cap = p.noise ? (int)p.noise_stride : 0;
+
+    QuadState s;
+    s.mn = __builtin_inff();
+    s.mx = -__builtin_inff();
+    s.rootp = 0.0;
+    s.consumed = 0;
+    s.path_total = 0;
+    s.status = 0;
+
+    for (int n = q.b; n < p.n_nodes; n += 16) {
+        Node z;
+        z.visit = 0;
+        z.vsum = 0.0f;
+        z.prior = 0.0f;
+        z.reward = 0.0f;
+        L.nodes[n] = z;
+        L.cb[n] = 0;
+    }
+    if (q.b == 0) L.path[0] = make_uint2(0u, 0u); /* the root: reward 0 */
+    double nz = S > 0 ? quad_noise_prefetch<NA>(s, q, noise, noise_cap) : 0.0;
+
+    /* root: representation -> prediction -> expand (mcts.py:88-123) */
+    f32x4 pr;
+    if (kInjected) {
 #pragma unroll
-    for (int a = 0; a < NA; ++a) L.onehot[a * 64 + lane] = w[m.d_in.w_off + (SD + a) * 64 + lane];
-
-    WaveLds T;  /* wave_backup only touches nodes / path */
-    T.nodes = L.nodes;
-    T.cb = L.cb;
-    T.path = L.path;
-    T.xh = T.xa = T.xb = T.ob = nullptr;
-    for (int i = lane; i < S + 2; i += kWave) L.pbc[i] = p.pbc[i];
+        for (int r = 0; r < 4; ++r) pr[r] = r < NA ? p.t_root_policy[(size_t)g * NA + r] : 0.0f;
+    } else {
+        for (int k = q.b; k < m.obs_dim; k += 16) L.trunk[q.c * 64 + k] = p.obs[(size_t)g * m.obs_dim + k];
+        wave_sync();
+        quad_representation<SD, NA, H>(m, L, q, L.hid);
+        (void)quad_prediction<SD, NA, H>(W, L, q, L.hid, &pr);
+    }
+    if (q.b == 0) {
+#pragma unroll
+        for (int r = 0; r < NA; ++r) L.nodes[1 + r].prior = pr[r];
+        L.cb[0] = 1;
+    }
+    wave_sync();
+    {
+        /* add_exploration_noise_at_the_root (mcts.py:134-145): f32 product widened, f64 sum */
+        constexpr int NAL = NA <= 2 ? 2 : 4;
+        const int a = q.b & (NAL - 1);
+        if (a < NA) {
+            const float pa = L.nodes[1 + a].prior;
+            if (p.train && S > 0)
+                s.rootp = (double)(pa * p.omf32) + p.dirichlet[(size_t)g * NA + a] * p.frac;
+            else
+                s.rootp = (double)pa;
+        }
+    }
 
 #ifdef MZS_DIAG
     unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    for (int g = blockIdx.x * (blockDim.x >> 6) + wave; g < p.n_games; g += n_waves) {
-        DIAG_T(tg0);
-        SearchConst c;
-        c.A = NA;
-        c.S = S;
-        c.n_nodes = p.n_nodes;
-        c.g32 = p.g32;
-        c.pbc = p.pbc;
-        c.noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
-        c.noise_cap = p.noise ? p.noise_stride : 0;
-
-        FastState s;
-        s.mn = __builtin_inff();
-        s.mx = -__builtin_inff();
-        s.consumed = 0;
-        s.win_base = 0;
-        s.path_total = 0;
-        s.status = 0;
-        s.maxd = 1;
-
-        for (int n = lane; n < p.n_nodes; n += kWave) {
-            Node z;
-            z.visit = 0;
-            z.vsum = 0.0f;
-            z.prior = 0.0f;
-            z.reward = 0.0f;
-            L.nodes[n] = z;
-            L.cb[n] = 0;
-            L.best[n] = 0;
-            L.meta[n] = 1u << 16; /* root children: parent 0, depth 1 */
-        }
-        for (int k = lane; k < m.obs_dim; k += kWave) L.xo[k] = p.obs[(size_t)g * m.obs_dim + k];
-        if (S > 0) fast_noise_refill(c, s, L, lane);
+    for (int sim = 0; sim < S; ++sim) {
+        DIAG_T(t0);
+        L.nwin[q.lane] = nz;
         wave_sync();
-
-        /* root: Representation_function.forward (weights streamed once from L2) */
-        {
-            float acc = w[m.r_in.b_off + lane];
-            for (int k = 0; k < m.obs_dim; ++k)
-                acc = mzs_fma(w[m.r_in.w_off + k * 64 + lane], L.xo[k], acc);
-            L.xa[lane] = mzs_elu(acc);
-            wave_sync();
-            acc = w[m.r_out.b_off + lane];
-#pragma unroll 8
-            for (int k = 0; k < H; ++k) acc = mzs_fma(w[m.r_out.w_off + k * 64 + lane], L.xa[k], acc);
-            const bool valid = lane < SD;
-            const float ninf = -__builtin_inff();
-            const float mx = halves_max(valid ? acc : ninf).lo;
-            const float mn = -halves_max(valid ? -acc : ninf).lo;
-            const float sc = mzs_bound_scale(mn, mx);
-            if (valid) L.hid[lane] = (acc - mn) / sc;
-            wave_sync();
-        }
-        float pr;
-        (void)fast_prediction<SD, NA, H>(W, L, L.hid, &pr, lane);
-        double rootp = 0.0;
-        if (lane < NA) {
-            L.nodes[1 + lane].prior = pr;
-            /* add_exploration_noise_at_the_root (mcts.py:134-145): f32 product widened, f64 sum */
-            if (p.train && S > 0)
-                rootp = (double)(pr * p.omf32) + p.dirichlet[(size_t)g * NA + lane] * p.frac;
-            else
-                rootp = (double)pr;
-            L.rootp[lane] = rootp;
-        }
-        if (lane == 0) L.cb[0] = 1;
-        wave_sync();
-
-        DIAG_T(tg1);
-        DIAG_ADD(0, tg0, tg1);
-        for (int sim = 0; sim < S; ++sim) {
-            int depth, action, pbase;
-            DIAG_T(t0);
-            const int leaf = fast_select<NA>(c, s, L, sim, &depth, &action, &pbase, lane);
-            DIAG_T(t1);
-            const int e_new = sim + 1, e_parent = (pbase - 1) / NA;
+        const QuadSelect<NA> sel = quad_select<NA>(L, s, q, noise, noise_cap, p.g32, sim);
+        nz = quad_noise_prefetch<NA>(s, q, noise, noise_cap);
+        DIAG_T(t1);
+        const int e_new = sim + 1;
+        float reward, value;
+        if (kInjected) {
+            reward = p.t_reward[(size_t)g * S + sim];
+            value = p.t_value[(size_t)g * S + sim];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) pr[r] = r < NA ? p.t_prior[((size_t)g * S + sim) * NA + r] : 0.0f;
+        } else {
+            /* dynamics on the parent's hidden state, prediction on the new one (mcts.py:180-192) */
+            const int e_parent = (sel.pbase - 1) / NA;
             float* hn = L.hid + e_new * 32;
-            const float reward =
-                fast_dynamics<SD, NA, H>(W, L, L.hid + e_parent * 32, action, hn, lane);
+            reward = low_half(quad_dynamics<SD, NA, H>(W, L, q, L.hid + e_parent * 32, sel.action, hn));
             DIAG_T(t2);
-            const float value = fast_prediction<SD, NA, H>(W, L, hn, &pr, lane);
-            DIAG_T(t3);
-            /* expand (mcts.py:186-200) */
-            const int cbase = 1 + e_new * NA;
-            if (lane < NA) {
-                L.nodes[cbase + lane].prior = pr;
-                L.meta[cbase + lane] = (unsigned)leaf | ((unsigned)(depth + 1) << 16);
-            }
-            if (lane == 0) {
-                L.nodes[leaf].reward = reward;
-                L.cb[leaf] = (unsigned short)cbase;
-                L.leafs[sim] = (unsigned short)leaf;
-            }
-            s.maxd = depth + 1 > s.maxd ? depth + 1 : s.maxd;
-            wave_sync();
-            wave_backup(c, s, T, depth, value, lane);
-            DIAG_T(t4);
-            DIAG_ADD(1, t0, t1);
             DIAG_ADD(2, t1, t2);
-            DIAG_ADD(3, t2, t3);
-            DIAG_ADD(4, t3, t4);
+            value = high_half(quad_prediction<SD, NA, H>(W, L, q, hn, &pr));
         }
-        DIAG_T(tg2);
+        DIAG_T(t3);
+        /* expand (mcts.py:186-200) */
+        const int cbase = 1 + e_new * NA;
+        if (q.b == 0) {
+#pragma unroll
+            for (int r = 0; r < NA; ++r) L.nodes[cbase + r].prior = pr[r];
+            L.nodes[sel.leaf].reward = reward;
+            L.cb[sel.leaf] = (unsigned short)cbase;
+            L.leafs[sim] = (unsigned short)sel.leaf;
+            L.path[sel.depth].y = __float_as_uint(reward);
+        }
+        wave_sync();
+        quad_backup(L, s, q, sel.depth, value, p.g32);
+        DIAG_T(t4);
+        DIAG_ADD(1, t0, t1);
+        DIAG_ADD(3, t1, t3);
+        DIAG_ADD(4, t3, t4);
+    }
 
-        /* tree + hidden states -> HBM structure of arrays; results (mcts.py:215-222) */
+    /* tree + hidden states -> HBM structure of arrays; results (mcts.py:215-222) */
+    if (live) {
         const size_t row = (size_t)g * p.t.stride;
-        for (int n = lane; n < p.n_nodes; n += kWave) {
+        for (int n = q.b; n < p.n_nodes; n += 16) {
             const Node nd = L.nodes[n];
             p.t.visit[row + n] = nd.visit;
             p.t.vsum[row + n] = nd.vsum;
@@ -420,17 +403,20 @@ __global__ void __launch_bounds__(256, MZS_FAST_WAVES) k_search_fast(const Searc
             p.t.reward[row + n] = nd.reward;
             p.t.child_base[row + n] = L.cb[n];
         }
-        for (int i = lane; i < S; i += kWave) p.t.sim_leaf[(size_t)g * p.t.max_sims + i] = L.leafs[i];
-        float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * p.t.hid_stride;
-        for (int i = lane; i < (S + 1) * 32; i += kWave) {
-            const int e = i >> 5, k = i & 31;
-            if (k < SD) hid_g[(size_t)e * p.t.hid_stride + k] = L.hid[i];
+        for (int i = q.b; i < S; i += 16) p.t.sim_leaf[(size_t)g * p.t.max_sims + i] = L.leafs[i];
+        if (!kInjected) {
+            float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * p.t.hid_stride;
+            for (int i = q.b; i < (S + 1) * 32; i += 16) {
+                const int e = i >> 5, k = i & 31;
+                if (k < SD) hid_g[(size_t)e * p.t.hid_stride + k] = L.hid[i];
+            }
         }
-        if (lane < NA) {
-            p.r.visits[(size_t)g * NA + lane] = L.nodes[1 + lane].visit;
-            p.r.root_prior[(size_t)g * NA + lane] = rootp;
+        constexpr int NAL = NA <= 2 ? 2 : 4;
+        if (q.b < NAL && q.b < NA) {
+            p.r.visits[(size_t)g * NA + q.b] = L.nodes[1 + q.b].visit;
+            p.r.root_prior[(size_t)g * NA + q.b] = s.rootp;
         }
-        if (lane == 0) {
+        if (q.b == 0) {
             const Node r = L.nodes[0];
             p.r.root_value[g] = r.visit == 0 ? 0.0f : r.vsum / (float)r.visit;
             p.r.consumed[g] = s.consumed;
@@ -439,12 +425,9 @@ __global__ void __launch_bounds__(256, MZS_FAST_WAVES) k_search_fast(const Searc
             p.t.minmax[2 * (size_t)g + 1] = s.mx;
             p.t.status[g] = s.status;
         }
-        wave_sync();
-        DIAG_T(tg3);
-        DIAG_ADD(5, tg2, tg3);
     }
 #ifdef MZS_DIAG
-    if (lane == 0)
+    if (q.lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_diag[i], dsum[i]);
 #endif
 }
@@ -614,48 +597,62 @@ int launch(K kernel, const P& params, int units, const LdsLayout& lds, hipStream
     return MZS_OK;
 }
 
-FastLayout make_fast_layout(const Model& m, int n_nodes, int S) {
-    FastLayout l;
+/* LDS plan of k_search_quad (mzs_quad.h QuadLayout) */
+QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model) {
+    QuadLayout l;
+    l.off_onehot = round_up((S + 2) * 8, 16);
+    l.shared_bytes = l.off_onehot + (with_model ? A * 64 * 4 : 0);
+    l.off_nwin = 4 * 64 * 4;
+    l.off_games = l.off_nwin + 64 * 8;
     int off = round_up(n_nodes * (int)sizeof(Node), 16);
-    l.off_cb = off;
+    l.g_cb = off;
     off += round_up(n_nodes * 2, 16);
-    l.off_path = off;
-    off += round_up((S + 2) * 2, 16);
-    l.off_meta = off;
-    off += round_up(n_nodes * 4, 16);
-    l.off_best = off;
-    off += round_up(n_nodes * 2, 16);
-    l.off_leafs = off;
-    off += round_up((S + 1) * 2, 16);
-    l.off_pbc = off;
+    l.g_path = off;
     off += round_up((S + 2) * 8, 16);
-    l.off_nwin = off;
-    off += kNoiseWin * 8;
-    l.off_rootp = off;
-    off += round_up(m.A * 8, 16);
-    l.off_hid = off;
-    off += (S + 1) * 32 * 4;
-    l.off_xa = off;
-    off += 64 * 4;
-    l.off_onehot = off;
-    off += m.A * 64 * 4;
-    l.off_xo = off;
-    off += 64 * 4;
-    l.bytes = round_up(off, 16);
+    l.g_hid = off;
+    off += with_model ? (S + 1) * 32 * 4 : 0;
+    l.g_leafs = off;
+    off += round_up((S + 1) * 2, 16);
+    l.g_bytes = off;
+    l.wave_bytes = l.off_games + 4 * l.g_bytes;
     return l;
 }
 
-/* the (S_dim, A, H) shapes the register-resident kernel is instantiated for */
-typedef void (*fast_kernel_t)(const SearchParams, const FastLayout);
-fast_kernel_t pick_fast_kernel(const mzs_dims& d) {
+/* the (S_dim, A, H) shapes the four-games-per-wave kernel is instantiated for */
+typedef void (*quad_kernel_t)(const SearchParams, const QuadLayout);
+quad_kernel_t pick_quad_kernel(const mzs_dims& d) {
     if (d.n_mid_layers != 0 || d.obs_dim > 64) return nullptr;
-    if (d.state_dim == 31 && d.n_actions == 2 && d.hidden_dim == 64) return k_search_fast<31, 2, 64>;
-    if (d.state_dim == 31 && d.n_actions == 4 && d.hidden_dim == 64) return k_search_fast<31, 4, 64>;
-    if (d.state_dim == 11 && d.n_actions == 2 && d.hidden_dim == 16) return k_search_fast<11, 2, 16>;
+    if (d.state_dim == 31 && d.n_actions == 2 && d.hidden_dim == 64) return k_search_quad<31, 2, 64, false>;
+    if (d.state_dim == 31 && d.n_actions == 4 && d.hidden_dim == 64) return k_search_quad<31, 4, 64, false>;
+    if (d.state_dim == 11 && d.n_actions == 2 && d.hidden_dim == 16) return k_search_quad<11, 2, 16, false>;
     return nullptr;
 }
 
-int launch_fast(mzs_handle* h, fast_kernel_t kernel, const SearchParams& p, hipStream_t st);
+quad_kernel_t pick_quad_injected(int A) {
+    if (A == 2) return k_search_quad<31, 2, 64, true>;
+    if (A == 3) return k_search_quad<31, 3, 64, true>;
+    if (A == 4) return k_search_quad<31, 4, 64, true>;
+    return nullptr;
+}
+
+/* waves per block that fit the LDS; 0 = the trees of four games do not fit at all */
+int quad_waves_per_block(const QuadLayout& l) {
+    int w = 4;
+    while (w > 0 && l.shared_bytes + w * l.wave_bytes > kMaxLdsPerBlock) --w;
+    return w;
+}
+
+int launch_quad(quad_kernel_t kernel, const SearchParams& p, const QuadLayout& ql, int wpb, hipStream_t st) {
+    const size_t shmem = (size_t)ql.shared_bytes + (size_t)wpb * ql.wave_bytes;
+    if (shmem > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    const int per_block = 4 * wpb;
+    const int blocks = (p.n_games + per_block - 1) / per_block;
+    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(wpb * kWave), shmem, st, p, ql);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
 
 int check_search_args(mzs_handle* h, int n_games, int S, int train, const double* dirichlet,
                       const double* noise, int64_t stride) {
@@ -688,24 +685,6 @@ void fill_search_params(mzs_handle* h, SearchParams* p, int n_games, int S, int 
     p->dirichlet = dirichlet;
     p->noise = S > 0 ? noise : nullptr;
     p->noise_stride = stride;
-}
-
-int launch_fast(mzs_handle* h, fast_kernel_t kernel, const SearchParams& p, hipStream_t st) {
-    const FastLayout fl = make_fast_layout(p.m, p.n_nodes, p.S);
-    const int wpb = 4;
-    const size_t shared_w = 2 * (size_t)((p.m.Sd + 3) / 4) * 64 * 4 * sizeof(float);
-    const size_t shmem = shared_w + (size_t)wpb * fl.bytes;
-    if (shmem > (size_t)kMaxLdsPerBlock) return fail(MZS_E_ARG, "fast kernel LDS slice too large");
-    if (shmem > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    /* 2 waves per SIMD are resident (register-limited): 2 blocks of 4 waves per CU */
-    int blocks = (p.n_games + wpb - 1) / wpb;
-    const int resident = MZS_FAST_WAVES * h->n_cus;
-    if (blocks > resident) blocks = resident;
-    hipLaunchKernelGGL(kernel, dim3(blocks), dim3(wpb * kWave), shmem, st, p, fl);
-    HIP_TRY(hipGetLastError());
-    return MZS_OK;
 }
 
 }  // namespace
@@ -858,9 +837,13 @@ int mzs_search(mzs_handle* h, int32_t n_games, int32_t S, int32_t train, const f
     SearchParams p;
     fill_search_params(h, &p, n_games, S, train, dirichlet_dev, noise_dev, noise_stride);
     p.obs = obs_dev;
-    fast_kernel_t fk = h->cfg.engine == MZS_ENGINE_FUSED ? pick_fast_kernel(h->cfg.dims) : nullptr;
-    if (fk && make_fast_layout(p.m, p.n_nodes, S).bytes * 4 <= kMaxLdsPerBlock / 2)
-        return launch_fast(h, fk, p, static_cast<hipStream_t>(stream));
+    if (h->cfg.engine == MZS_ENGINE_FUSED && mzs_max_draws(h->cfg.dims.n_actions, S) < (1ll << 31)) {
+        if (quad_kernel_t qk = pick_quad_kernel(h->cfg.dims)) {
+            const QuadLayout ql = make_quad_layout(p.m.A, p.n_nodes, S, true);
+            const int wpb = quad_waves_per_block(ql);
+            if (wpb > 0) return launch_quad(qk, p, ql, wpb, static_cast<hipStream_t>(stream));
+        }
+    }
     return launch(k_search_fused<false>, p, n_games, p.lds, static_cast<hipStream_t>(stream));
 }
 
@@ -881,6 +864,13 @@ int mzs_search_injected(mzs_handle* h, int32_t n_games, int32_t S, int32_t train
     p.t_reward = sim_reward_dev;
     p.t_value = sim_value_dev;
     p.t_prior = sim_prior_dev;
+    if (h->cfg.engine == MZS_ENGINE_FUSED && mzs_max_draws(h->cfg.dims.n_actions, S) < (1ll << 31)) {
+        if (quad_kernel_t qk = pick_quad_injected(h->cfg.dims.n_actions)) {
+            const QuadLayout ql = make_quad_layout(p.m.A, p.n_nodes, S, false);
+            const int wpb = quad_waves_per_block(ql);
+            if (wpb > 0) return launch_quad(qk, p, ql, wpb, static_cast<hipStream_t>(stream));
+        }
+    }
     return launch(k_search_fused<true>, p, n_games, p.lds, static_cast<hipStream_t>(stream));
 }
 

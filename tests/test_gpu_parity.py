@@ -25,21 +25,27 @@ def same_bits(a, b):
     return np.array_equal(bits(np.asarray(a)), bits(np.asarray(b)))
 
 
-def make_engine(d, G, S, gamma, frac=0.25):
+ENGINES = ["fused", "generic"]   # fused = k_search_quad where the shape has one; generic = k_search_fused
+
+
+def make_engine(d, G, S, gamma, frac=0.25, engine="fused"):
+    from muzero_amd import _lib
     from muzero_amd.engine import SearchEngine
     return SearchEngine((d.obs_dim, d.n_actions, d.state_dim, d.hidden_dim, d.n_mid_layers),
                         max_games=G, max_simulations=S, discount=gamma,
-                        root_exploration_fraction=frac)
+                        root_exploration_fraction=frac,
+                        engine=_lib.ENGINE_FUSED if engine == "fused" else _lib.ENGINE_FUSED_GENERIC)
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("fname,tag", SEARCH_FIXTURES)
-def test_L1_search_injected_bit_exact(fname, tag):
+def test_L1_search_injected_bit_exact(fname, tag, engine):
     """Search kernels alone: the reference's own model outputs injected."""
     fx = load_golden(fname)
     d, _ = fixture_weights(tag)
     S, G = int(fx["S"]), len(fx["seed"])
     dirichlet, noise = fixture_streams(fx)
-    eng = make_engine(d, G, S, float(fx["gamma"]), float(fx["frac"]))
+    eng = make_engine(d, G, S, float(fx["gamma"]), float(fx["frac"]), engine)
     assert np.array_equal(eng.pbc[: S + 1], fx["pbc_table"][: S + 1])
     train = bool(fx["train"])
     eng.search_injected(table_of(fx), dirichlet if train and S > 0 else None,
@@ -89,8 +95,9 @@ def test_L2_inference_kernels(tag):
     eng.close()
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("fname,tag", SEARCH_FIXTURES)
-def test_L3_search_end_to_end(fname, tag):
+def test_L3_search_end_to_end(fname, tag, engine):
     """Full search on the GPU: bit-exact vs the oracle on every game; vs the reference,
     identical visit counts on every search without a near-tie."""
     from oracle import mz_oracle as mzo
@@ -99,7 +106,7 @@ def test_L3_search_end_to_end(fname, tag):
     S, G = int(fx["S"]), len(fx["seed"])
     dirichlet, noise = fixture_streams(fx)
     train = bool(fx["train"])
-    eng = make_engine(d, G, S, float(fx["gamma"]), float(fx["frac"]))
+    eng = make_engine(d, G, S, float(fx["gamma"]), float(fx["frac"]), engine)
     eng.set_weights(blob)
     eng.search(fx["obs"], dirichlet if train and S > 0 else None, noise if S > 0 else None, S, train)
     out = eng.results_host()
@@ -131,6 +138,54 @@ def test_L3_search_end_to_end(fname, tag):
         assert value_err(out["root_value"][same], fx["root_value"][same]).max() <= 1
         t0 = np.argmax(out["visits"], axis=1)
         assert np.array_equal(t0[same], fx["t0_action"][same])
+    eng.close()
+
+
+FULL_WANT = ("visits", "root_value", "root_prior", "consumed", "path_len", "sim_leaf", "node_visit",
+             "node_vsum", "node_reward", "node_prior", "child_base", "minmax", "hidden")
+
+
+def assert_search_equals_oracle(out, tree, ref):
+    assert np.array_equal(out["visits"], ref["visits"])
+    assert same_bits(out["root_value"], ref["root_value"])
+    assert same_bits(out["root_prior"], ref["root_prior"])
+    assert np.array_equal(out["consumed"], ref["consumed"])
+    assert np.array_equal(out["path_len"], ref["path_len"])
+    assert np.array_equal(tree["sim_leaf"], ref["sim_leaf"])
+    assert np.array_equal(tree["visit"], ref["node_visit"])
+    assert np.array_equal(tree["child_base"], ref["child_base"])
+    assert same_bits(tree["value_sum"], ref["node_vsum"])
+    assert same_bits(tree["reward"], ref["node_reward"])
+    assert same_bits(tree["prior"], ref["node_prior"])
+    assert same_bits(tree["minmax"], ref["minmax"])
+    assert same_bits(tree["hidden"], ref["hidden"])
+
+
+@pytest.mark.parametrize("shape", [(8, 4, 31, 64, 0), (4, 2, 31, 64, 0), (4, 2, 11, 16, 0)])
+@pytest.mark.parametrize("G,S", [(37, 50), (5, 7), (1, 50)])
+def test_quad_shapes_vs_oracle(shape, G, S):
+    """Every shape k_search_quad is instantiated for (incl. the LunarLander-like A = 4 one, which no
+    shipped checkpoint covers), ragged game counts (partial waves / blocks), seeded random
+    weights: fused engine == oracle on every output bit.  The oracle is pinned to the reference
+    by tests/test_oracle_golden.py; these weights have no reference run (parity vs oracle only)."""
+    from muzero_amd import rng
+    from oracle import mz_oracle as mzo
+    d = mzo.dims(*shape)
+    rs = np.random.RandomState(1000 * sum(shape) + 10 * G + S)
+    from muzero_amd.model import blob_layout
+    n_w = sum(int(np.prod(shp)) for _, shp in blob_layout(*shape))
+    blob = (rs.standard_normal(n_w) * 0.3).astype(np.float32)
+    A = shape[1]
+    obs = rs.uniform(-1, 1, size=(G, shape[0])).astype(np.float32)
+    dirichlet, noise = rng.noise_streams(np.arange(G) + 77, A, S, 0.25, True)
+    eng = make_engine(d, G, S, 0.997)
+    eng.set_weights(blob)
+    eng.search(obs, dirichlet, noise, S, True)
+    out, tree = eng.results_host(), eng.tree_host()
+    ref = mzo.search(d, blob, S, 0.997, 0.25, eng.pbc, obs=obs, dirichlet=dirichlet, noise=noise,
+                     train=True, want=FULL_WANT)
+    assert not tree["status"].any()
+    assert_search_equals_oracle(out, tree, ref)
     eng.close()
 
 
