@@ -73,28 +73,36 @@ MZS_FN float mzs_exp_reduce(float x, int* n_out) {
     return r;
 }
 
-/* exp(x); results below FLT_MIN flush to 0, inputs above 88 saturate. */
+/* exp(x); results below FLT_MIN flush to 0, inputs above 88 saturate.  Branch-free on
+ * purpose: on the GPU four of these run interleaved in one basic block. */
 MZS_FN float mzs_expf(float x) {
-    if (x < -87.0f) return 0.0f;
-    if (x > 88.0f) x = 88.0f;
+    float xc = x > 88.0f ? 88.0f : x;
+    xc = xc < -87.0f ? -87.0f : xc;
     int n;
-    float r = mzs_exp_reduce(x, &n);
+    float r = mzs_exp_reduce(xc, &n);
     float e = mzs_expm1_poly(r) + 1.0f;
-    return e * mzs_pow2i(n);
+    e = e * mzs_pow2i(n);
+    return x < -87.0f ? 0.0f : e;
 }
 
-/* expm1(x) for x <= 0: 2^n * (e^r - 1) + (2^n - 1), one fma at the end. */
+/* expm1(x) for x <= 0: 2^n * (e^r - 1) + (2^n - 1), one fma at the end (branch-free;
+ * x > 0 is evaluated as x = 0). */
 MZS_FN float mzs_expm1f_neg(float x) {
-    if (x < -87.0f) return -1.0f;
+    float xc = x > 0.0f ? 0.0f : x;
+    xc = xc < -87.0f ? -87.0f : xc;
     int n;
-    float r = mzs_exp_reduce(x, &n);
+    float r = mzs_exp_reduce(xc, &n);
     float p = mzs_expm1_poly(r);
     float s = mzs_pow2i(n);
-    return mzs_fma(s, p, s - 1.0f);
+    float y = mzs_fma(s, p, s - 1.0f);
+    return x < -87.0f ? -1.0f : y;
 }
 
 /* torch.nn.ELU(alpha=1) */
-MZS_FN float mzs_elu(float x) { return x > 0.0f ? x : mzs_expm1f_neg(x); }
+MZS_FN float mzs_elu(float x) {
+    float y = mzs_expm1f_neg(x);
+    return x > 0.0f ? x : y;
+}
 
 /* Scalar tail of inverse_transform_with_support (muzero_model.py:585-586). */
 MZS_FN float mzs_inverse_value_transform(float y) {

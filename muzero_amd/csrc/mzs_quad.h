@@ -82,7 +82,8 @@ __device__ __forceinline__ float high_half(float v) {
     return hi;
 }
 
-__device__ __forceinline__ float fmax_sel(float a, float b) { return b > a ? b : a; }
+/* no NaNs on this path; v_max_f32 instead of compare + select */
+__device__ __forceinline__ float fmax_sel(float a, float b) { return __builtin_fmaxf(a, b); }
 
 /* reductions over the 8 blocks of this lane's half, per game (result in every lane of the half) */
 __device__ __forceinline__ float half_sum(float v) {
@@ -139,24 +140,36 @@ struct QuadWeights {
     f32x4 b_d_in, b_d_h, b_p_in, b_p_h;
 };
 
+/* 16-byte tree node of this kernel: everything pUCT reads about a child in one ds_read_b128.
+ * x0 = reward + f32(gamma) * value() is refreshed by backup (the un-normalised value score of
+ * mcts.py:158-160); value sums live in their own array. */
+struct __attribute__((aligned(16))) QNode {
+    unsigned vc;   /* child_base | visit_count << 16 */
+    float x0;
+    float prior;
+    float reward;
+};
+
 /* per-wave LDS */
 struct QuadLds {
     float* trunk;            /* [4][64] trunk activations, game-major                      */
     double* nwin;            /* [64] tie-break draws of the next descent: [level][a][game]  */
     const float* onehot;     /* block-shared [NA][64] action columns of the dynamics input  */
     const double* pbc;       /* block-shared [S+2] sqrt(n) * pb_c(n)                        */
+    const double* inv64;     /* block-shared [S+2] 1/n, correctly rounded                   */
+    const float* inv32;      /* block-shared [S+2] 1/n, correctly rounded                   */
     /* this lane's game */
-    Node* nodes;
-    unsigned short* cb;
+    QNode* nodes;
+    float* vsum;             /* [n_nodes] Node.value_sum                                    */
     uint2* path;             /* [S+2] {node, reward bits}                                   */
     float* hid;              /* [S+1][32]                                                   */
     unsigned short* leafs;   /* [S]                                                         */
 };
 
 struct QuadLayout {
-    int off_onehot, shared_bytes;              /* block-shared part: pbc at 0           */
-    int off_nwin, off_games, wave_bytes;       /* per wave: trunk at 0                  */
-    int g_cb, g_path, g_hid, g_leafs, g_bytes; /* per game: nodes at 0                  */
+    int off_inv64, off_inv32, off_onehot, shared_bytes; /* block-shared part: pbc at 0  */
+    int off_nwin, off_games, wave_bytes;                /* per wave: trunk at 0         */
+    int g_vsum, g_path, g_hid, g_leafs, g_bytes;        /* per game: nodes at 0         */
 };
 
 template <int SD, int NA, int H>
@@ -206,7 +219,10 @@ __device__ __forceinline__ f32x4 quad_softmax(const f32x4 o, const bool (&valid)
                                         valid[2] ? o[2] : ninf, valid[3] ? o[3] : ninf}));
     f32x4 e;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) e[r] = valid[r] ? mzs_expf(o[r] - m) : 0.0f;
+    for (int r = 0; r < 4; ++r) {
+        const float ex = mzs_expf(o[r] - m);
+        e[r] = valid[r] ? ex : 0.0f;
+    }
     const float Z = half_sum(sum4(e));
 #pragma unroll
     for (int r = 0; r < 4; ++r) e[r] = e[r] / Z;
@@ -318,8 +334,27 @@ __device__ __forceinline__ void quad_representation(const Model& m, const QuadLd
 
 /* ------------------------------------------------------------------ search */
 
+/* a / d given r = RN(1/d): product, then fma residual corrections (Markstein).  Each step
+ * takes a faithful quotient to the correctly rounded one; one step is exhaustively verified for
+ * fp32 with integer d <= 512 (tests/test_division.py), elsewhere two steps are used.  No
+ * overflow / underflow on this path: operands are visit counts, values and priors. */
+__device__ __forceinline__ float div_r1(float a, float d, float r) {
+    const float q = a * r;
+    return mzs_fma(mzs_fma(-q, d, a), r, q);
+}
+__device__ __forceinline__ float div_r2(float a, float d, float r) {
+    const float q = div_r1(a, d, r);
+    return mzs_fma(mzs_fma(-q, d, a), r, q);
+}
+__device__ __forceinline__ double div_r2(double a, double d, double r) {
+    double q = a * r;
+    q = __builtin_fma(__builtin_fma(-q, d, a), r, q);
+    return __builtin_fma(__builtin_fma(-q, d, a), r, q);
+}
+
 struct QuadState {
     float mn, mx;       /* MinMaxStats of this lane's game        */
+    float rinv;         /* 1 / (mx - mn), refreshed by backup      */
     double rootp;       /* root-child prior of (game, a) after noise */
     int consumed;       /* tie-break draws consumed               */
     int path_total;
@@ -341,27 +376,31 @@ __device__ __forceinline__ void quad_argmax_step(double& bs, int& ba, unsigned& 
     const unsigned op = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pay, kCtrl, 0xF, 0xF, false);
     const float orw = dpp_mov<kCtrl>(rew);
     /* ties -> larger action (mcts.py:167) */
-    const bool take = (os > bs) || (os == bs && oa > ba);
+    const bool take = (os > bs) | ((os == bs) & (oa > ba));
     bs = take ? os : bs;
     ba = take ? oa : ba;
     pay = take ? op : pay;
     rew = take ? orw : rew;
 }
 
-/* Descent of the four games at once, one tree level per iteration (mcts.py:155-177).
- * Lane (c, a) scores child a of game c's current node; games that reached a leaf idle. */
 template <int NA>
 struct QuadSelect {
     int leaf, depth, action, pbase;
 };
 
+/* Descent of the four games at once, one tree level per iteration (mcts.py:155-177).
+ * Lane (c, a) scores child a of game c's current node; games that reached a leaf idle.
+ * Straight-line per level: no data-dependent branches. */
 template <int NA>
 __device__ __forceinline__ QuadSelect<NA> quad_select(const QuadLds& L, QuadState& s, const QuadLane& q,
                                                       const double* __restrict__ noise, int noise_cap,
-                                                      float g32, int sim) {
+                                                      int sim) {
     constexpr int NAL = NA <= 2 ? 2 : 4; /* lanes per sibling group */
     constexpr int kWin = 16 / NAL;       /* levels held by the LDS window */
     const int a = q.b & (NAL - 1);
+    const int aa = a < NA ? a : 0;
+    const bool norm = s.mx > s.mn;
+    const float rng = s.mx - s.mn;
     QuadSelect<NA> r;
     r.leaf = 0, r.depth = 0, r.action = 0, r.pbase = 0;
     int cbn = 1;     /* the root is expanded: its children start at node 1 */
@@ -369,44 +408,39 @@ __device__ __forceinline__ QuadSelect<NA> quad_select(const QuadLds& L, QuadStat
     for (int t = 0;; ++t) {
         const bool active = cbn != 0;
         if (__builtin_amdgcn_ballot_w64(active) == 0) break;
-        const int child = (active ? cbn : 1) + (a < NA ? a : 0);
-        const Node ch = L.nodes[child];
-        const int ccb = L.cb[child];
-        const double tn = L.pbc[pv];
-        double u;
-        if (t < kWin) {
-            u = L.nwin[(t * NAL + a) * 4 + q.c];
-        } else {
-            const int ni = s.consumed + t * NA + a;
-            u = (noise && a < NA && ni < noise_cap) ? noise[ni] : 0.0;
+        if (t > 0 && (t & (kWin - 1)) == 0) {
+            /* deeper than the window: fetch the next kWin levels' draws */
+            wave_sync();
+            const int ni = s.consumed + (t + q.b / NAL) * NA + a;
+            L.nwin[q.lane] = (noise && a < NA && ni < noise_cap) ? noise[ni] : 0.0;
+            wave_sync();
         }
+        const int child = (active ? cbn : 1) + aa;
+        const QNode ch = L.nodes[child];
+        const double tn = L.pbc[pv];
+        const int n = (int)(ch.vc >> 16);
+        const double iv = L.inv64[n + 1];
+        const double u = L.nwin[((t & (kWin - 1)) * NAL + a) * 4 + q.c];
         /* ucb_score (mcts.py:155-163) */
         const double pd = t == 0 ? s.rootp : (double)ch.prior;
-        const double ps = (tn * pd) / (double)(ch.visit + 1);
-        double vs = 0.0;
-        if (ch.visit > 0) {
-            const float qv = ch.vsum / (float)ch.visit;
-            float x = g32 * qv;
-            x = ch.reward + x;
-            if (s.mx > s.mn) x = (x - s.mn) / (s.mx - s.mn);
-            vs = (double)x;
-        }
+        const double ps = div_r2(tn * pd, (double)(n + 1), iv);
+        const float xn = div_r2(ch.x0 - s.mn, rng, s.rinv);
+        const float x = norm ? xn : ch.x0;
+        const double vs = n > 0 ? (double)x : 0.0;
         double bs = (ps + vs) + u;
-        if (NA < NAL && a >= NA) bs = -__builtin_inf();
+        if (NA < NAL) bs = a < NA ? bs : -__builtin_inf();
         int ba = a;
-        unsigned pay = (unsigned)ccb | ((unsigned)ch.visit << 16);
+        unsigned pay = ch.vc;
         float rew = ch.reward;
         if (NAL == 4) quad_argmax_step<kDppRowRor8>(bs, ba, pay, rew);
         quad_argmax_step<kDppRowRor4>(bs, ba, pay, rew);
-        if (active) {
-            r.pbase = cbn;
-            r.action = ba;
-            r.leaf = cbn + ba;
-            r.depth += 1;
-            pv = (int)(pay >> 16);
-            cbn = (int)(pay & 0xffffu);
-            if (q.b == 0) L.path[r.depth] = make_uint2((unsigned)r.leaf, __float_as_uint(rew));
-        }
+        r.pbase = active ? cbn : r.pbase;
+        r.action = active ? ba : r.action;
+        r.leaf = active ? cbn + ba : r.leaf;
+        r.depth += active ? 1 : 0;
+        pv = active ? (int)(pay >> 16) : pv;
+        if (active && q.b == 0) L.path[r.depth] = make_uint2((unsigned)r.leaf, __float_as_uint(rew));
+        cbn = active ? (int)(pay & 0xffffu) : 0;
     }
     s.consumed += NA * r.depth;
     if (s.consumed > noise_cap) s.status = 1;
@@ -436,7 +470,7 @@ __device__ __forceinline__ void quad_backup(const QuadLds& L, QuadState& s, cons
     dmax = max(dmax, __builtin_amdgcn_update_dpp(0, dmax, kDppQuadXor2, 0xF, 0xF, false));
     dmax = __builtin_amdgcn_readfirstlane(dmax);
     const int slot = q.b & (kChunk - 1);
-    const float pinf = __builtin_inff();
+    const float ninf = -__builtin_inff();
     float v = value;
     for (int hi = dmax; hi >= 0; hi -= kChunk) {
         float rw[kChunk];
@@ -444,8 +478,10 @@ __device__ __forceinline__ void quad_backup(const QuadLds& L, QuadState& s, cons
         for (int k = 0; k < kChunk; ++k) rw[k] = __uint_as_float(L.path[hi - k > 0 ? hi - k : 0].y);
         const int lvl = hi - slot;
         const bool mine = q.b < kChunk && lvl >= 0 && lvl <= depth;
-        const int pn = (int)L.path[mine ? lvl : 0].x;
-        const int2 rec = *reinterpret_cast<const int2*>(&L.nodes[pn]);
+        const uint2 pe = L.path[mine ? lvl : 0];
+        const int pn = (int)pe.x;
+        const unsigned vc = L.nodes[pn].vc;
+        const float vs0 = L.vsum[pn];
         float myv = 0.0f;
 #pragma unroll
         for (int k = 0; k < kChunk; ++k) {
@@ -455,19 +491,22 @@ __device__ __forceinline__ void quad_backup(const QuadLds& L, QuadState& s, cons
             const float nv = rw[k] + gv;
             v = on ? nv : v;
         }
-        float qv = 0.0f;
+        const int visit = (int)(vc >> 16) + 1;
+        const float vsum = vs0 + myv;
+        const float qv = div_r1(vsum, (float)visit, L.inv32[visit]);
         if (mine) {
-            const float vsum = __int_as_float(rec.y) + myv;
-            const int visit = rec.x + 1;
-            qv = vsum / (float)visit;
-            *reinterpret_cast<int2*>(&L.nodes[pn]) = make_int2(visit, __float_as_int(vsum));
+            const float gq = g32 * qv;
+            const float x0 = __uint_as_float(pe.y) + gq;
+            *reinterpret_cast<uint2*>(&L.nodes[pn]) = make_uint2(vc + 0x10000u, __float_as_uint(x0));
+            L.vsum[pn] = vsum;
         }
-        const float qmx = game_max(mine ? qv : -pinf);
-        const float qmn = -game_max(mine ? -qv : -pinf);
-        s.mx = qmx > s.mx ? qmx : s.mx;
-        s.mn = qmn < s.mn ? qmn : s.mn;
+        const float qmx = game_max(mine ? qv : ninf);
+        const float qmn = -game_max(mine ? -qv : ninf);
+        s.mx = fmax_sel(s.mx, qmx);
+        s.mn = __builtin_fminf(s.mn, qmn);
         wave_sync();
     }
+    s.rinv = 1.0f / (s.mx - s.mn);
 }
 
 }  // namespace mzs

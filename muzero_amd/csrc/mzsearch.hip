@@ -266,8 +266,14 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
 
     /* block-shared tables, then the only block-level barrier */
     double* pbc_s = reinterpret_cast<double*>(smem);
+    double* inv64_s = reinterpret_cast<double*>(smem + ql.off_inv64);
+    float* inv32_s = reinterpret_cast<float*>(smem + ql.off_inv32);
     float* onehot_s = reinterpret_cast<float*>(smem + ql.off_onehot);
-    for (int i = threadIdx.x; i < S + 2; i += blockDim.x) pbc_s[i] = p.pbc[i];
+    for (int i = threadIdx.x; i < S + 2; i += blockDim.x) {
+        pbc_s[i] = p.pbc[i];
+        inv64_s[i] = 1.0 / (double)(i > 0 ? i : 1); /* correctly rounded reciprocals (div_r*) */
+        inv32_s[i] = 1.0f / (float)(i > 0 ? i : 1);
+    }
     QuadWeights<SD, NA, H> W;
     if (!kInjected) {
         for (int i = threadIdx.x; i < NA * 64; i += blockDim.x)
@@ -288,8 +294,10 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
     L.nwin = reinterpret_cast<double*>(wbase + ql.off_nwin);
     L.onehot = onehot_s;
     L.pbc = pbc_s;
-    L.nodes = reinterpret_cast<Node*>(gbase);
-    L.cb = reinterpret_cast<unsigned short*>(gbase + ql.g_cb);
+    L.inv64 = inv64_s;
+    L.inv32 = inv32_s;
+    L.nodes = reinterpret_cast<QNode*>(gbase);
+    L.vsum = reinterpret_cast<float*>(gbase + ql.g_vsum);
     L.path = reinterpret_cast<uint2*>(gbase + ql.g_path);
     L.hid = reinterpret_cast<float*>(gbase + ql.g_hid);
     L.leafs = reinterpret_cast<unsigned short*>(gbase + ql.g_leafs);
@@ -300,19 +308,20 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
     QuadState s;
     s.mn = __builtin_inff();
     s.mx = -__builtin_inff();
+    s.rinv = 0.0f;
     s.rootp = 0.0;
     s.consumed = 0;
     s.path_total = 0;
     s.status = 0;
 
     for (int n = q.b; n < p.n_nodes; n += 16) {
-        Node z;
-        z.visit = 0;
-        z.vsum = 0.0f;
+        QNode z;
+        z.vc = 0u;
+        z.x0 = 0.0f;
         z.prior = 0.0f;
         z.reward = 0.0f;
         L.nodes[n] = z;
-        L.cb[n] = 0;
+        L.vsum[n] = 0.0f;
     }
     if (q.b == 0) L.path[0] = make_uint2(0u, 0u); /* the root: reward 0 */
     double nz = S > 0 ? quad_noise_prefetch<NA>(s, q, noise, noise_cap) : 0.0;
@@ -331,7 +340,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
     if (q.b == 0) {
 #pragma unroll
         for (int r = 0; r < NA; ++r) L.nodes[1 + r].prior = pr[r];
-        L.cb[0] = 1;
+        L.nodes[0].vc = 1u;
     }
     wave_sync();
     {
@@ -354,7 +363,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
         DIAG_T(t0);
         L.nwin[q.lane] = nz;
         wave_sync();
-        const QuadSelect<NA> sel = quad_select<NA>(L, s, q, noise, noise_cap, p.g32, sim);
+        const QuadSelect<NA> sel = quad_select<NA>(L, s, q, noise, noise_cap, sim);
         nz = quad_noise_prefetch<NA>(s, q, noise, noise_cap);
         DIAG_T(t1);
         const int e_new = sim + 1;
@@ -380,7 +389,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
 #pragma unroll
             for (int r = 0; r < NA; ++r) L.nodes[cbase + r].prior = pr[r];
             L.nodes[sel.leaf].reward = reward;
-            L.cb[sel.leaf] = (unsigned short)cbase;
+            L.nodes[sel.leaf].vc = (unsigned)cbase; /* never visited before its expansion */
             L.leafs[sim] = (unsigned short)sel.leaf;
             L.path[sel.depth].y = __float_as_uint(reward);
         }
@@ -396,12 +405,12 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
     if (live) {
         const size_t row = (size_t)g * p.t.stride;
         for (int n = q.b; n < p.n_nodes; n += 16) {
-            const Node nd = L.nodes[n];
-            p.t.visit[row + n] = nd.visit;
-            p.t.vsum[row + n] = nd.vsum;
+            const QNode nd = L.nodes[n];
+            p.t.visit[row + n] = (int)(nd.vc >> 16);
+            p.t.vsum[row + n] = L.vsum[n];
             p.t.prior[row + n] = nd.prior;
             p.t.reward[row + n] = nd.reward;
-            p.t.child_base[row + n] = L.cb[n];
+            p.t.child_base[row + n] = (int)(nd.vc & 0xffffu);
         }
         for (int i = q.b; i < S; i += 16) p.t.sim_leaf[(size_t)g * p.t.max_sims + i] = L.leafs[i];
         if (!kInjected) {
@@ -413,12 +422,12 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
         }
         constexpr int NAL = NA <= 2 ? 2 : 4;
         if (q.b < NAL && q.b < NA) {
-            p.r.visits[(size_t)g * NA + q.b] = L.nodes[1 + q.b].visit;
+            p.r.visits[(size_t)g * NA + q.b] = (int)(L.nodes[1 + q.b].vc >> 16);
             p.r.root_prior[(size_t)g * NA + q.b] = s.rootp;
         }
         if (q.b == 0) {
-            const Node r = L.nodes[0];
-            p.r.root_value[g] = r.visit == 0 ? 0.0f : r.vsum / (float)r.visit;
+            const int rv = (int)(L.nodes[0].vc >> 16);
+            p.r.root_value[g] = rv == 0 ? 0.0f : L.vsum[0] / (float)rv;
             p.r.consumed[g] = s.consumed;
             p.r.path_len[g] = s.path_total;
             p.t.minmax[2 * (size_t)g] = s.mn;
@@ -600,13 +609,15 @@ int launch(K kernel, const P& params, int units, const LdsLayout& lds, hipStream
 /* LDS plan of k_search_quad (mzs_quad.h QuadLayout) */
 QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model) {
     QuadLayout l;
-    l.off_onehot = round_up((S + 2) * 8, 16);
+    l.off_inv64 = round_up((S + 2) * 8, 16);
+    l.off_inv32 = 2 * l.off_inv64;
+    l.off_onehot = l.off_inv32 + round_up((S + 2) * 4, 16);
     l.shared_bytes = l.off_onehot + (with_model ? A * 64 * 4 : 0);
     l.off_nwin = 4 * 64 * 4;
     l.off_games = l.off_nwin + 64 * 8;
-    int off = round_up(n_nodes * (int)sizeof(Node), 16);
-    l.g_cb = off;
-    off += round_up(n_nodes * 2, 16);
+    int off = n_nodes * (int)sizeof(QNode);
+    l.g_vsum = off;
+    off += round_up(n_nodes * 4, 16);
     l.g_path = off;
     off += round_up((S + 2) * 8, 16);
     l.g_hid = off;

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Diagnostic (not a benchmark): per-phase share of wave cycles in the fast fused kernel,
+"""Diagnostic (not a benchmark): per-phase share of wave cycles in k_search_quad,
 from a -DMZS_DIAG build of the library (s_memtime stamps).  Usage on the GPU box:
 MZS_LIB=$PWD/muzero_amd/libmzsearch_diag.so python profiles/diag_phases.py"""
 import ctypes as C
@@ -26,9 +26,12 @@ for it in range(3):
     eng.results_host()
     lib.mzs_debug_counters(out)
 v = np.array(list(out), dtype=np.float64)
-names = ["root(init+repr+pred)", "select", "dynamics", "prediction", "expand+backup", "writeout", "-", "-"]
+# k_search_quad: one wave = 4 games; counters are summed over waves (lane 0 of each)
+v[3] -= v[2]
+names = ["-", "select", "dynamics", "prediction", "expand+backup", "-", "-", "-"]
 tot = v.sum()
+W = G / 4
 for n, x in zip(names, v):
     if x:
-        print(f"{n:22s} {x / (G * S):10.1f} cycles per sim   {100 * x / tot:5.1f} %")
-print(f"total {tot / (G * S):.1f} cycles per game-sim (stamps cost ~40 cycles each)")
+        print(f"{n:22s} {x / (W * S):10.1f} cycles per wave-sim (4 games)   {100 * x / tot:5.1f} %")
+print(f"total {tot / (W * S):.1f} cycles per wave-sim (stamps cost ~40 cycles each)")
