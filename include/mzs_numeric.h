@@ -10,8 +10,12 @@
  *
  * Contract (every operation is an individually rounded IEEE-754 binary32 op;
  * compile with -ffp-contract=off on both sides):
- *   dot      : acc = bias; for k ascending: acc = fma(w[k], x[k], acc)
- *              (== what v_mfma_f32_*_f32 computes: a k-ordered fmaf chain)
+ *   dot      : two interleaved fma chains, then one add:
+ *                e = bias; for even k ascending: e = fma(w[k], x[k], e)
+ *                o = +0;   for odd  k ascending: o = fma(w[k], x[k], o)
+ *                y = e + o
+ *              (an f32 MFMA is bitwise a k-ordered fmaf chain; two independent accumulators
+ *              keep the matrix pipe issuing back to back instead of waiting on one chain)
  *   sum      : adjacent-pair tree over the array zero-padded to a power of two
  *              (v[i] = v[2i] + v[2i+1], repeated) == lane-local pair sum followed by a
  *              wave xor-butterfly (a + b == b + a bitwise)

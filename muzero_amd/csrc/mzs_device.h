@@ -162,7 +162,7 @@ __device__ __forceinline__ void wave_dense(const float* __restrict__ w, const La
     for (int j0 = 0; j0 < ly.n_pad; j0 += kWave) {
         const int j = j0 + lane;
         const float* __restrict__ wt = w + ly.w_off + j;
-        float acc = w[ly.b_off + j];
+        float acc = w[ly.b_off + j], odd = 0.0f;
         int k = 0;
         for (; k + 4 <= ly.k; k += 4) {
             const float4 xv = *reinterpret_cast<const float4*>(x + k);
@@ -171,11 +171,17 @@ __device__ __forceinline__ void wave_dense(const float* __restrict__ w, const La
             const float w2 = wt[(size_t)(k + 2) * ly.n_pad];
             const float w3 = wt[(size_t)(k + 3) * ly.n_pad];
             acc = mzs_fma(w0, xv.x, acc);
-            acc = mzs_fma(w1, xv.y, acc);
+            odd = mzs_fma(w1, xv.y, odd);
             acc = mzs_fma(w2, xv.z, acc);
-            acc = mzs_fma(w3, xv.w, acc);
+            odd = mzs_fma(w3, xv.w, odd);
         }
-        for (; k < ly.k; ++k) acc = mzs_fma(wt[(size_t)k * ly.n_pad], x[k], acc);
+        for (; k < ly.k; ++k) {
+            if (k & 1)
+                odd = mzs_fma(wt[(size_t)k * ly.n_pad], x[k], odd);
+            else
+                acc = mzs_fma(wt[(size_t)k * ly.n_pad], x[k], acc);
+        }
+        acc = acc + odd;
         if (extra_row >= 0) acc = acc + wt[(size_t)extra_row * ly.n_pad];
         if (kElu) acc = mzs_elu(acc);
         out[j] = acc;

@@ -115,13 +115,24 @@ __device__ __forceinline__ float max4(const f32x4 v) {
     return fmax_sel(fmax_sel(v[0], v[1]), fmax_sel(v[2], v[3]));
 }
 
-/* one fma-chain step for k = K0 .. K-1: acc[r] = fma(w[k], x[k], acc[r]) for the four games */
+/* contract "dot" for the four games: even k accumulate into e (starts at the bias), odd k
+ * into o (starts at zero); two independent MFMA chains issue back to back */
 template <int K, int k = 0>
-__device__ __forceinline__ void quad_chain(const float* w, const float* x, f32x4& acc) {
+__device__ __forceinline__ void quad_chain2(const float* w, const float* x, f32x4& e, f32x4& o) {
     if constexpr (k < K) {
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[k], x[k & 15], acc, 0, 0, 4 + (k >> 4));
-        quad_chain<K, k + 1>(w, x, acc);
+        if constexpr (k & 1)
+            o = __builtin_amdgcn_mfma_f32_4x4x1f32(w[k], x[k & 15], o, 0, 0, 4 + (k >> 4));
+        else
+            e = __builtin_amdgcn_mfma_f32_4x4x1f32(w[k], x[k & 15], e, 0, 0, 4 + (k >> 4));
+        quad_chain2<K, k + 1>(w, x, e, o);
     }
+}
+
+template <int K>
+__device__ __forceinline__ f32x4 quad_dense(const float* w, const float* x, const f32x4 bias) {
+    f32x4 e = bias, o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    quad_chain2<K>(w, x, e, o);
+    return e + o;
 }
 
 /* B-operand registers: x[q] = row[16 * g + q] */
@@ -261,11 +272,9 @@ __device__ __forceinline__ float quad_prediction(const QuadWeights<SD, NA, H>& W
                                                  const QuadLane& q, const float* h, f32x4* prior) {
     float x[16];
     quad_load_x(h, q.grp & 1, x);
-    f32x4 acc = W.b_p_in;
-    quad_chain<SD>(W.p_in, x, acc);
+    f32x4 acc = quad_dense<SD>(W.p_in, x, W.b_p_in);
     quad_trunk_to_x(L, q, acc, x);
-    acc = W.b_p_h;
-    quad_chain<H>(W.p_h, x, acc);
+    acc = quad_dense<H>(W.p_h, x, W.b_p_h);
     const int i0 = 4 * q.eb, lim = q.half ? SD : NA;
     const bool valid[4] = {i0 < lim, i0 + 1 < lim, i0 + 2 < lim, i0 + 3 < lim};
     const f32x4 p = quad_softmax(acc, valid);
@@ -283,13 +292,11 @@ __device__ __forceinline__ float quad_dynamics(const QuadWeights<SD, NA, H>& W, 
     float x[16];
     quad_load_x(h, q.grp & 1, x);
     const float4 oh = *reinterpret_cast<const float4*>(L.onehot + action * 64 + q.n0);
-    f32x4 acc = W.b_d_in;
-    quad_chain<SD>(W.d_in, x, acc);
+    f32x4 acc = quad_dense<SD>(W.d_in, x, W.b_d_in);
     /* one-hot action column (muzero_model.py:502): fma(1, w, acc) == acc + w */
     acc = f32x4{acc[0] + oh.x, acc[1] + oh.y, acc[2] + oh.z, acc[3] + oh.w};
     quad_trunk_to_x(L, q, acc, x);
-    acc = W.b_d_h;
-    quad_chain<H>(W.d_h, x, acc);
+    acc = quad_dense<H>(W.d_h, x, W.b_d_h);
     const int i0 = 4 * q.eb;
     const bool valid[4] = {i0 < SD, i0 + 1 < SD, i0 + 2 < SD, i0 + 3 < SD};
     /* reward head */
@@ -313,18 +320,22 @@ __device__ __forceinline__ void quad_representation(const Model& m, const QuadLd
         const float4 v = *reinterpret_cast<const float4*>(w + off + q.n0);
         return f32x4{v.x, v.y, v.z, v.w};
     };
-    f32x4 acc = b4(m.r_in.b_off);
-    for (int k = 0; k < m.obs_dim; ++k)
-        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w[m.r_in.w_off + k * 64 + n], L.trunk[q.c * 64 + k], acc,
-                                                 0, 0, 0);
+    f32x4 acc = b4(m.r_in.b_off), odd = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < m.obs_dim; ++k) {
+        const float wk = w[m.r_in.w_off + k * 64 + n], xk = L.trunk[q.c * 64 + k];
+        if (k & 1)
+            odd = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, xk, odd, 0, 0, 0);
+        else
+            acc = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, xk, acc, 0, 0, 0);
+    }
+    acc = acc + odd;
     wave_sync();
     float x[16];
     quad_trunk_to_x(L, q, acc, x);
-    acc = b4(m.r_out.b_off);
     float wk[H];
 #pragma unroll
     for (int k = 0; k < H; ++k) wk[k] = w[m.r_out.w_off + k * 64 + n];
-    quad_chain<H>(wk, x, acc);
+    acc = quad_dense<H>(wk, x, b4(m.r_out.b_off));
     const int i0 = 4 * q.eb;
     const bool valid[4] = {i0 < SD, i0 + 1 < SD, i0 + 2 < SD, i0 + 3 < SD};
     const f32x4 y = quad_scale_to_bound(acc, valid);

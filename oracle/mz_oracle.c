@@ -12,14 +12,16 @@
 
 /* ------------------------------------------------------------------ model */
 
-/* y[j] = bias[j] then k-ordered fma chain (contract "dot"). W row-major [nout][ldw]. */
+/* contract "dot": even-k chain from the bias, odd-k chain from zero, one add.
+ * W row-major [nout][ldw]. */
 static void dense(const float* W, const float* b, const float* x, int nout, int nin, int ldw,
                   float* y) {
     for (int j = 0; j < nout; ++j) {
-        float acc = b[j];
+        float e = b[j], o = 0.0f;
         const float* w = W + (size_t)j * ldw;
-        for (int k = 0; k < nin; ++k) acc = mzs_fma(w[k], x[k], acc);
-        y[j] = acc;
+        for (int k = 0; k < nin; k += 2) e = mzs_fma(w[k], x[k], e);
+        for (int k = 1; k < nin; k += 2) o = mzs_fma(w[k], x[k], o);
+        y[j] = e + o;
     }
 }
 
