@@ -110,6 +110,13 @@ int mzs_results(mzs_handle* h, int32_t n_games, int32_t* visits_dev, float* root
 #define MZS_TREE_MINMAX 6      /* f32 [G][2]       MinMaxStats minimum, maximum     */
 #define MZS_TREE_HIDDEN 7      /* f32 [G][max_simulations+1][mzs_hidden_stride(h)]  */
 #define MZS_TREE_STATUS 8      /* i32 [G]          0 ok, 1 noise stream exhausted   */
+/* the arrays mzs_results copies from (zero-copy access for callers that read in place) */
+#define MZS_TREE_ROOT_VISITS 9 /* i32 [G][A]       root-child visit counts          */
+#define MZS_TREE_ROOT_VALUE 10 /* f32 [G]          root.value(); starts right behind the visit
+                                  counts of max_games games (one copy reads both)   */
+#define MZS_TREE_ROOT_PRIOR 11 /* f64 [G][A]       root-child priors after noise    */
+#define MZS_TREE_CONSUMED 12   /* i64 [G]          tie-break draws consumed         */
+#define MZS_TREE_PATH_LEN 13   /* i64 [G]          selections made                  */
 void* mzs_tree_array(mzs_handle* h, int32_t which);
 int32_t mzs_tree_stride(const mzs_handle* h);
 int32_t mzs_hidden_stride(const mzs_handle* h);

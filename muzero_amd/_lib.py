@@ -16,6 +16,7 @@ ENGINE_FUSED_GENERIC = 2
 
 TREE_VISIT, TREE_VALUE_SUM, TREE_PRIOR, TREE_REWARD, TREE_CHILD_BASE = 0, 1, 2, 3, 4
 TREE_SIM_LEAF, TREE_MINMAX, TREE_HIDDEN, TREE_STATUS = 5, 6, 7, 8
+TREE_ROOT_VISITS, TREE_ROOT_VALUE, TREE_ROOT_PRIOR, TREE_CONSUMED, TREE_PATH_LEN = 9, 10, 11, 12, 13
 
 
 class MzsError(RuntimeError):

@@ -372,10 +372,16 @@ struct QuadState {
     int status;
 };
 
+/* row rotations read a valid lane everywhere: bound_ctrl spares the zero-initialised destination */
+template <int kCtrl>
+__device__ __forceinline__ int quad_dpp_i32(int v) {
+    return __builtin_amdgcn_mov_dpp(v, kCtrl, 0xF, 0xF, true);
+}
+
 template <int kCtrl>
 __device__ __forceinline__ double quad_dpp_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), kCtrl, 0xF, 0xF, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), kCtrl, 0xF, 0xF, false);
+    const int lo = quad_dpp_i32<kCtrl>(__double2loint(v));
+    const int hi = quad_dpp_i32<kCtrl>(__double2hiint(v));
     return __hiloint2double(hi, lo);
 }
 
@@ -383,9 +389,9 @@ __device__ __forceinline__ double quad_dpp_f64(double v) {
 template <int kCtrl>
 __device__ __forceinline__ void quad_argmax_step(double& bs, int& ba, unsigned& pay, float& rew) {
     const double os = quad_dpp_f64<kCtrl>(bs);
-    const int oa = __builtin_amdgcn_update_dpp(0, ba, kCtrl, 0xF, 0xF, false);
-    const unsigned op = (unsigned)__builtin_amdgcn_update_dpp(0, (int)pay, kCtrl, 0xF, 0xF, false);
-    const float orw = dpp_mov<kCtrl>(rew);
+    const int oa = quad_dpp_i32<kCtrl>(ba);
+    const unsigned op = (unsigned)quad_dpp_i32<kCtrl>((int)pay);
+    const float orw = __int_as_float(quad_dpp_i32<kCtrl>(__float_as_int(rew)));
     /* ties -> larger action (mcts.py:167) */
     const bool take = (os > bs) | ((os == bs) & (oa > ba));
     bs = take ? os : bs;

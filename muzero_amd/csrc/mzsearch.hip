@@ -772,14 +772,14 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
         (rc = dev_alloc(h, &h->tree.minmax, G * 2)) ||
         (rc = dev_alloc(h, &h->tree.hidden, G * (Smax + 1) * h->tree.hid_stride)) ||
         (rc = dev_alloc(h, &h->tree.status, G)) ||
-        (rc = dev_alloc(h, &h->res.visits, G * A)) ||
-        (rc = dev_alloc(h, &h->res.root_value, G)) ||
+        (rc = dev_alloc(h, &h->res.visits, G * A + G)) || /* root values right behind: one read-back */
         (rc = dev_alloc(h, &h->res.root_prior, G * A)) ||
         (rc = dev_alloc(h, &h->res.consumed, G)) ||
         (rc = dev_alloc(h, &h->res.path_len, G))) {
         mzs_destroy(h);
         return rc;
     }
+    h->res.root_value = reinterpret_cast<float*>(h->res.visits + G * A);
     if (cfg->max_simulations > 0) {
         hipError_t e = hipMemcpy(h->pbc_dev, cfg->pbc_table, (Smax + 1) * sizeof(double),
                                  hipMemcpyHostToDevice);
@@ -918,6 +918,11 @@ void* mzs_tree_array(mzs_handle* h, int32_t which) {
         case MZS_TREE_MINMAX: return h->tree.minmax;
         case MZS_TREE_HIDDEN: return h->tree.hidden;
         case MZS_TREE_STATUS: return h->tree.status;
+        case MZS_TREE_ROOT_VISITS: return h->res.visits;
+        case MZS_TREE_ROOT_VALUE: return h->res.root_value;
+        case MZS_TREE_ROOT_PRIOR: return h->res.root_prior;
+        case MZS_TREE_CONSUMED: return h->res.consumed;
+        case MZS_TREE_PATH_LEN: return h->res.path_len;
         default: return nullptr;
     }
 }

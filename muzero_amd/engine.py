@@ -142,6 +142,30 @@ class SearchEngine:
                                         _ptr(out["path_len"]), self._stream()), "mzs_results")
         return out
 
+    def results_view(self):
+        """Zero-copy torch views of the handle's result arrays (same keys as results()); valid
+        until the next search on this engine."""
+        G, A = self.n_games, self.A
+        spec = dict(visits=(_lib.TREE_ROOT_VISITS, (G, A), "<i4"),
+                    root_value=(_lib.TREE_ROOT_VALUE, (G,), "<f4"),
+                    root_prior=(_lib.TREE_ROOT_PRIOR, (G, A), "<f8"),
+                    consumed=(_lib.TREE_CONSUMED, (G,), "<i8"),
+                    path_len=(_lib.TREE_PATH_LEN, (G,), "<i8"))
+        if not hasattr(self, "_views") or self._views[0] != G:
+            out = {}
+            for k, (which, shape, ts) in spec.items():
+                p = self.lib.mzs_tree_array(self.h, which)
+                out[k] = torch.as_tensor(_DevView(p, shape, ts), device=self.device)
+            self._views = (G, out)
+        return self._views[1]
+
+    def results_packed_view(self):
+        """One int32 view [max_games * (A + 1)] over visit counts (max_games x A) followed by the
+        root values' bits (max_games): a single device->host copy reads both."""
+        n = self.max_games * (self.A + 1)
+        p = self.lib.mzs_tree_array(self.h, _lib.TREE_ROOT_VISITS)
+        return torch.as_tensor(_DevView(p, (n,), "<i4"), device=self.device)
+
     def results_host(self):
         out = self.results()
         torch.cuda.synchronize(self.device)

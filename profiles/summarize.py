@@ -23,7 +23,7 @@ def main():
     lines += ["## kernel-trace --stats", "", "| kernel | calls | total ns | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|---|"]
     for r in st:
         lines.append(f"| {r['Name'][:90]} | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {r['Percentage']} |")
-    for name in ("fetch", "write", "sq"):
+    for name in ("fetch", "write", "sq", "mfma"):
         pm = rows(os.path.join(src, f"pmc_{name}", "**", "*counter_collection.csv"))
         agg = {}
         for r in pm:
@@ -34,7 +34,7 @@ def main():
         lines += ["", f"## --pmc pass: {name} (mean per launch)", "", "| kernel | counter | mean | launches |", "|---|---|---|---|"]
         for (k, c), (s, n) in sorted(agg.items()):
             lines.append(f"| {k} | {c} | {s / n:.1f} | {n} |")
-    for name in ("trace", "fetch", "write", "sq"):
+    for name in ("trace", "fetch", "write", "sq", "mfma"):
         p = os.path.join(src, f"bench_{name}.json")
         if os.path.exists(p):
             txt = open(p).read().strip().splitlines()
