@@ -138,6 +138,37 @@ int mzs_recurrent_inference(mzs_handle* h, int32_t batch, const float* hidden_de
 int mzs_prediction_inference(mzs_handle* h, int32_t batch, const float* hidden_dev,
                              float* policy_dev, float* value_dev, void* stream);
 
+/* ---- training step (the reference's Muzero.train, muzero_model.py:791-811) ----------------
+ * Optimizer state and the step counter live in the handle; weights are the ones of
+ * mzs_set_weights and every mzs_train_apply refreshes what the search / inference kernels read. */
+#define MZS_OPT_ADAM 0 /* torch.optim.Adam(lr, betas 0.9/0.999, eps 1e-8), muzero_model.py:419 */
+#define MZS_OPT_SGD 1  /* torch.optim.SGD(lr, momentum 0.9), muzero_model.py:421               */
+
+/* Allocates the per-sample tapes for batches of up to max_batch samples (this rank's shard) and
+ * k_hypothetical_steps = unroll_steps (muzero_model.py:623), and zeroed optimizer state. */
+int mzs_train_create(mzs_handle* h, int32_t max_batch, int32_t unroll_steps);
+
+/* reshape_batch -> compute_forward -> evaluate_loss -> backward (muzero_model.py:440-472,
+ * :609-647, :650-734, :757-759) on `batch` samples, up to the optimizer step:
+ *   obs_dev [B][obs_dim]; actions_dev [K][B][A] one-hot (zeros = absorbing, replay_buffer.py:120);
+ *   target_value_dev / target_reward_dev [K][B]; target_policy_dev [K][B][A];
+ *   is_ratio_dev [B] importance-sampling ratio or NULL (uniform sampling, replay_buffer.py:165);
+ *   inv_global_batch = 1 / (batch size over all data-parallel ranks)
+ * outputs: grad_dev [mzs_weight_count] in blob order (this shard's share: ranks SUM them),
+ *   loss_dev [3K] = the 3K-1 raw loss terms in store_loss order (shard's share of the batch mean)
+ *   then loss_nn; priority_dev [K][B] = |h^-1(value_k) - target_value_k| (muzero_model.py:710). */
+int mzs_train_grad(mzs_handle* h, int32_t batch, const float* obs_dev, const float* actions_dev,
+                   const float* target_value_dev, const float* target_reward_dev,
+                   const float* target_policy_dev, const float* is_ratio_dev, float inv_global_batch,
+                   float* grad_dev, float* loss_dev, float* priority_dev, void* stream);
+
+/* optimizer.step() (muzero_model.py:764) with the (all-reduced) gradient; lr is the scheduler's
+ * current value (muzero_amd/train.py evaluates the reference's schedulers on the host). */
+int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, double lr, void* stream);
+
+/* current weights in blob order, to a host or device buffer (synchronises the device) */
+int mzs_get_weights(mzs_handle* h, float* blob_out, size_t n_floats);
+
 const char* mzs_last_error(void);
 const char* mzs_version(void);
 

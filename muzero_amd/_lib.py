@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("MZS_LIB") or os.path.join(_HERE, "libmzsearch.so")
 ENGINE_FUSED = 0
 ENGINE_LOCKSTEP = 1
 ENGINE_FUSED_GENERIC = 2
+OPT_ADAM, OPT_SGD = 0, 1
 
 TREE_VISIT, TREE_VALUE_SUM, TREE_PRIOR, TREE_REWARD, TREE_CHILD_BASE = 0, 1, 2, 3, 4
 TREE_SIM_LEAF, TREE_MINMAX, TREE_HIDDEN, TREE_STATUS = 5, 6, 7, 8
@@ -56,6 +57,12 @@ _SIGNATURES = {
                                           C.c_void_p]),
     "mzs_prediction_inference": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p,
                                            C.c_void_p, C.c_void_p]),
+    "mzs_train_create": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "mzs_train_grad": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                                 C.c_void_p]),
+    "mzs_train_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
+    "mzs_get_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mzs_last_error": (C.c_char_p, []),
     "mzs_version": (C.c_char_p, []),
 }

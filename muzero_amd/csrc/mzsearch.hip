@@ -8,6 +8,7 @@
  */
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 #include <new>
@@ -17,6 +18,7 @@
 #include "../../include/mzsearch.h"
 #include "mzs_device.h"
 #include "mzs_quad.h"
+#include "mzs_train.h"
 
 using namespace mzs;
 
@@ -498,7 +500,16 @@ struct mzs_handle {
     TreeArrays tree;
     Results res;
     float* w_dev = nullptr;
+    float* blob_dev = nullptr;     /* master weights in blob order (include/mzs_layout.h)      */
+    int* store_index_dev = nullptr; /* blob element -> offset in the device weight store        */
     double* pbc_dev = nullptr;
+    /* training (mzs_train_*): allocated by mzs_train_create */
+    int train_batch = 0, train_K = 0, train_step = 0;
+    TapeLayout tape_layout;
+    float* tape_dev = nullptr;
+    float* loss_buf_dev = nullptr;
+    float* adam_m_dev = nullptr;
+    float* adam_v_dev = nullptr;
     size_t w_floats = 0;
     bool have_weights = false;
     int n_nodes_max = 0;
@@ -531,13 +542,24 @@ struct StoreBuilder {
         data.resize(data.size() + (size_t)n_pad, 0.0f);
         return ly;
     }
+    std::vector<int> index; /* blob element -> store offset (sized by the caller) */
+    size_t w0 = 0, b0 = 0;  /* blob offsets of the tensor being filled             */
     /* W is torch layout [n_out][ld]; copy rows [0,rows) of W^T into columns [col0, col0+n_out) */
     void fill(const Layer& ly, const float* W, const float* b, int n_out, int rows, int ld, int col0) {
         for (int j = 0; j < n_out; ++j) {
-            for (int k = 0; k < rows; ++k)
-                data[(size_t)ly.w_off + (size_t)k * ly.n_pad + col0 + j] = W[(size_t)j * ld + k];
+            for (int k = 0; k < rows; ++k) {
+                const size_t so = (size_t)ly.w_off + (size_t)k * ly.n_pad + col0 + j;
+                data[so] = W[(size_t)j * ld + k];
+                if (!index.empty()) index[w0 + (size_t)j * ld + k] = (int)so;
+            }
             data[(size_t)ly.b_off + col0 + j] = b[j];
+            if (!index.empty()) index[b0 + j] = (int)((size_t)ly.b_off + col0 + j);
         }
+    }
+    /* tensor at blob offsets (ow, ob) */
+    void fill_at(const Layer& ly, const float* B, size_t ow, size_t ob, int n_out, int rows, int ld, int col0) {
+        w0 = ow, b0 = ob;
+        fill(ly, B + ow, B + ob, n_out, rows, ld, col0);
     }
 };
 
@@ -761,7 +783,10 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     h->tree.max_sims = cfg->max_simulations;
     int rc = MZS_OK;
     const size_t ts = (size_t)h->tree.stride;
+    const size_t n_blob = mzs_blob_layout(&d).total;
     if ((rc = dev_alloc(h, &h->w_dev, h->w_floats)) ||
+        (rc = dev_alloc(h, &h->blob_dev, n_blob)) ||
+        (rc = dev_alloc(h, &h->store_index_dev, n_blob)) ||
         (rc = dev_alloc(h, &h->pbc_dev, Smax + 2)) ||
         (rc = dev_alloc(h, &h->tree.visit, G * ts)) ||
         (rc = dev_alloc(h, &h->tree.vsum, G * ts)) ||
@@ -817,19 +842,22 @@ int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats) {
     StoreBuilder sb;
     Model m;
     describe_model(d, &m, &sb);
-    sb.fill(m.r_in, B + o.r_in_w, B + o.r_in_b, H, ob, ob, 0);
-    sb.fill(m.r_out, B + o.r_out_w, B + o.r_out_b, Sd, H, H, 0);
-    sb.fill(m.d_in, B + o.d_in_w, B + o.d_in_b, H, Sd + A, Sd + A, 0);
-    sb.fill(m.d_heads, B + o.d_rew_w, B + o.d_rew_b, Sd, H, H, 0);
-    sb.fill(m.d_heads, B + o.d_st_w, B + o.d_st_b, Sd, H, H, m.seg_state);
-    sb.fill(m.p_in, B + o.p_in_w, B + o.p_in_b, H, Sd, Sd, 0);
-    sb.fill(m.p_heads, B + o.p_pol_w, B + o.p_pol_b, A, H, H, 0);
-    sb.fill(m.p_heads, B + o.p_val_w, B + o.p_val_b, Sd, H, H, m.seg_value);
+    sb.index.assign(n_floats, 0);
+    sb.fill_at(m.r_in, B, o.r_in_w, o.r_in_b, H, ob, ob, 0);
+    sb.fill_at(m.r_out, B, o.r_out_w, o.r_out_b, Sd, H, H, 0);
+    sb.fill_at(m.d_in, B, o.d_in_w, o.d_in_b, H, Sd + A, Sd + A, 0);
+    sb.fill_at(m.d_heads, B, o.d_rew_w, o.d_rew_b, Sd, H, H, 0);
+    sb.fill_at(m.d_heads, B, o.d_st_w, o.d_st_b, Sd, H, H, m.seg_state);
+    sb.fill_at(m.p_in, B, o.p_in_w, o.p_in_b, H, Sd, Sd, 0);
+    sb.fill_at(m.p_heads, B, o.p_pol_w, o.p_pol_b, A, H, H, 0);
+    sb.fill_at(m.p_heads, B, o.p_val_w, o.p_val_b, Sd, H, H, m.seg_value);
     if (d.n_mid_layers > 0) {
-        sb.fill(m.r_mid, B + o.r_mid_w, B + o.r_mid_b, H, H, H, 0);
-        sb.fill(m.d_mid, B + o.d_mid_w, B + o.d_mid_b, H, H, H, 0);
-        sb.fill(m.p_mid, B + o.p_mid_w, B + o.p_mid_b, H, H, H, 0);
+        sb.fill_at(m.r_mid, B, o.r_mid_w, o.r_mid_b, H, H, H, 0);
+        sb.fill_at(m.d_mid, B, o.d_mid_w, o.d_mid_b, H, H, H, 0);
+        sb.fill_at(m.p_mid, B, o.p_mid_w, o.p_mid_b, H, H, H, 0);
     }
+    HIP_TRY(hipMemcpy(h->blob_dev, B, n_floats * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(h->store_index_dev, sb.index.data(), n_floats * sizeof(int), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(h->w_dev, sb.data.data(), sb.data.size() * sizeof(float),
                       hipMemcpyHostToDevice));
     h->have_weights = true;
@@ -977,4 +1005,192 @@ int mzs_prediction_inference(mzs_handle* h, int32_t batch, const float* hidden_d
                          policy_dev, value_dev, stream);
 }
 
+/* ------------------------------------------------------------------ training step */
+
+static TapeLayout make_tape_layout(const Model& m, int K) {
+    TapeLayout t;
+    std::memset(&t, 0, sizeof t);
+    const int L = m.L;
+    t.HP = round_up(m.H, 64);
+    t.SP = round_up(m.Sd, 64);
+    t.AP = round_up(m.A, 64);
+    t.XP = round_up(m.Sd + m.A, 64);
+    t.OP = round_up(m.obs_dim, 64);
+    t.OPH = m.p_heads.n_pad;
+    t.ODH = m.d_heads.n_pad;
+    t.L = L;
+    t.K = K;
+    int off = 0;
+    t.r_x = off, off += t.OP;
+    t.r_T = off, off += (L + 1) * t.HP;
+    t.r_din = off, off += t.HP;
+    t.r_dmid = off, off += L * t.HP;
+    t.r_dout = off, off += t.SP;
+    t.p_base = off;
+    int r = 0;
+    t.p_h = r, r += t.SP;
+    t.p_T = r, r += (L + 1) * t.HP;
+    t.p_din = r, r += t.HP;
+    t.p_dmid = r, r += L * t.HP;
+    t.p_dpol = r, r += t.AP;
+    t.p_dval = r, r += t.SP;
+    t.p_out = r, r += t.OPH;
+    t.p_stride = r;
+    off += K * t.p_stride + t.SP; /* + one spare hidden-state row past the last record */
+    t.d_base = off;
+    r = 0;
+    t.d_x = r, r += t.XP;
+    t.d_T = r, r += (L + 1) * t.HP;
+    t.d_din = r, r += t.HP;
+    t.d_dmid = r, r += L * t.HP;
+    t.d_drew = r, r += t.SP;
+    t.d_dst = r, r += t.SP;
+    t.d_out = r, r += t.ODH;
+    t.d_stride = r;
+    off += (K > 1 ? K - 1 : 0) * t.d_stride;
+    t.copy_n = off;
+    t.s_zs = off, off += m.r_out.n_pad;
+    t.s_gT = off, off += t.HP;
+    t.s_gT2 = off, off += t.HP;
+    t.s_gh = off, off += t.XP;
+    t.s_ghn = off, off += t.XP;
+    t.s_scl = off, off += 4 * K;
+    t.total = off;
+    return t;
+}
+
+static void fill_tensor_descs(const mzs_dims& d, const TapeLayout& t, int K, TensorDesc* td) {
+    const mzs_blob_offsets o = mzs_blob_layout(&d);
+    const int H = d.hidden_dim, S = d.state_dim, A = d.n_actions, L = d.n_mid_layers, HP = t.HP;
+    const auto set = [&](int i, size_t w, size_t b, int n_out, int n_in, int x, int dl, int on, int os,
+                         int in, int l2) {
+        td[i].w_off = (int)w, td[i].b_off = (int)b, td[i].n_out = n_out, td[i].n_in = n_in;
+        td[i].x_off = x, td[i].d_off = dl, td[i].outer_n = on, td[i].outer_stride = os;
+        td[i].inner_n = in, td[i].inner_sx = HP, td[i].inner_sd = HP, td[i].l2 = l2;
+    };
+    const int Km = K > 1 ? K - 1 : 0, pb = t.p_base, db = t.d_base;
+    /* l2 (neural_network_mlp_model.py:280-285): zip() over the three parameter lists stops at the
+     * representation's length, so the next-state head and the value head are left out */
+    set(0, o.r_in_w, o.r_in_b, H, d.obs_dim, t.r_x, t.r_din, 1, 0, 1, 1);
+    set(1, o.r_mid_w, o.r_mid_b, L > 0 ? H : 0, H, t.r_T, t.r_dmid, 1, 0, L, 1);
+    set(2, o.r_out_w, o.r_out_b, S, H, t.r_T + L * HP, t.r_dout, 1, 0, 1, 1);
+    set(3, o.d_in_w, o.d_in_b, H, S + A, db + t.d_x, db + t.d_din, Km, t.d_stride, 1, 1);
+    set(4, o.d_mid_w, o.d_mid_b, L > 0 ? H : 0, H, db + t.d_T, db + t.d_dmid, Km, t.d_stride, L, 1);
+    set(5, o.d_rew_w, o.d_rew_b, S, H, db + t.d_T + L * HP, db + t.d_drew, Km, t.d_stride, 1, 1);
+    set(6, o.d_st_w, o.d_st_b, S, H, db + t.d_T + L * HP, db + t.d_dst, Km, t.d_stride, 1, 0);
+    set(7, o.p_in_w, o.p_in_b, H, S, pb + t.p_h, pb + t.p_din, K, t.p_stride, 1, 1);
+    set(8, o.p_mid_w, o.p_mid_b, L > 0 ? H : 0, H, pb + t.p_T, pb + t.p_dmid, K, t.p_stride, L, 1);
+    set(9, o.p_pol_w, o.p_pol_b, A, H, pb + t.p_T + L * HP, pb + t.p_dpol, K, t.p_stride, 1, 1);
+    set(10, o.p_val_w, o.p_val_b, S, H, pb + t.p_T + L * HP, pb + t.p_dval, K, t.p_stride, 1, 0);
+}
+
+int mzs_train_create(mzs_handle* h, int32_t max_batch, int32_t unroll_steps) {
+    if (!h) return fail(MZS_E_ARG, "null handle");
+    if (max_batch < 1 || unroll_steps < 1) return fail(MZS_E_ARG, "bad batch or unroll length");
+    const mzs_dims& d = h->cfg.dims;
+    if (d.state_dim > 64 || d.n_actions > 64)
+        return fail(MZS_E_ARG, "training kernels hold one logit per lane: state_dim and n_actions <= 64");
+    if (h->tape_dev) return fail(MZS_E_STATE, "mzs_train_create was already called on this handle");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    const TapeLayout t = make_tape_layout(h->model, unroll_steps);
+    if ((size_t)t.total * sizeof(float) > (size_t)kMaxLdsPerBlock)
+        return fail(MZS_E_ARG, "one sample's unroll does not fit 160 KiB of LDS");
+    const size_t n = mzs_blob_layout(&d).total;
+    int rc;
+    if ((rc = dev_alloc(h, &h->tape_dev, (size_t)max_batch * t.copy_n)) ||
+        (rc = dev_alloc(h, &h->loss_buf_dev, (size_t)max_batch * (3 * unroll_steps - 1))) ||
+        (rc = dev_alloc(h, &h->adam_m_dev, n)) || (rc = dev_alloc(h, &h->adam_v_dev, n)))
+        return rc;
+    h->tape_layout = t;
+    h->train_batch = max_batch;
+    h->train_K = unroll_steps;
+    h->train_step = 0;
+    return MZS_OK;
+}
+
+int mzs_train_grad(mzs_handle* h, int32_t batch, const float* obs_dev, const float* actions_dev,
+                   const float* target_value_dev, const float* target_reward_dev,
+                   const float* target_policy_dev, const float* is_ratio_dev, float inv_global_batch,
+                   float* grad_dev, float* loss_dev, float* priority_dev, void* stream) {
+    if (!h) return fail(MZS_E_ARG, "null handle");
+    if (!h->tape_dev) return fail(MZS_E_STATE, "mzs_train_create has not been called");
+    if (!h->have_weights) return fail(MZS_E_STATE, "mzs_set_weights has not been called");
+    if (batch < 1 || batch > h->train_batch) return fail(MZS_E_ARG, "batch exceeds max_batch of mzs_train_create");
+    if (!obs_dev || !actions_dev || !target_value_dev || !target_reward_dev || !target_policy_dev ||
+        !grad_dev || !loss_dev || !priority_dev)
+        return fail(MZS_E_ARG, "null buffer");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    TrainParams p;
+    std::memset(&p, 0, sizeof p);
+    p.m = h->model;
+    p.tl = h->tape_layout;
+    fill_tensor_descs(h->cfg.dims, p.tl, h->train_K, p.td);
+    p.bo = mzs_blob_layout(&h->cfg.dims);
+    p.blob = h->blob_dev;
+    p.B = batch;
+    p.K = h->train_K;
+    p.n_params = (int)p.bo.total;
+    p.inv_batch = inv_global_batch;
+    p.obs = obs_dev;
+    p.actions = actions_dev;
+    p.tv = target_value_dev;
+    p.tr = target_reward_dev;
+    p.tp = target_policy_dev;
+    p.is_ratio = is_ratio_dev;
+    p.tape = h->tape_dev;
+    p.loss_buf = h->loss_buf_dev;
+    p.priority = priority_dev;
+    p.grad = grad_dev;
+    p.loss_out = loss_dev;
+    const size_t shmem = (size_t)p.tl.total * sizeof(float);
+    if (shmem > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_sample),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(k_train_sample, dim3(batch), dim3(kWave), shmem, st, p);
+    HIP_TRY(hipGetLastError());
+    const int n_grad_blocks = (p.n_params + 255) / 256;
+    hipLaunchKernelGGL(k_train_wgrad, dim3(n_grad_blocks + 1), dim3(256), 0, st, p, n_grad_blocks);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
+int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, double lr, void* stream) {
+    if (!h || !grad_dev) return fail(MZS_E_ARG, "null argument");
+    if (!h->tape_dev) return fail(MZS_E_STATE, "mzs_train_create has not been called");
+    if (!h->have_weights) return fail(MZS_E_STATE, "mzs_set_weights has not been called");
+    if (optimizer != MZS_OPT_ADAM && optimizer != MZS_OPT_SGD) return fail(MZS_E_ARG, "unknown optimizer");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    h->train_step += 1;
+    ApplyParams p;
+    p.blob = h->blob_dev;
+    p.store = h->w_dev;
+    p.store_index = h->store_index_dev;
+    p.m = h->adam_m_dev;
+    p.v = h->adam_v_dev;
+    p.grad = grad_dev;
+    p.n = (int)mzs_blob_layout(&h->cfg.dims).total;
+    p.optimizer = optimizer;
+    p.step = h->train_step;
+    const double bc1 = 1.0 - std::pow(0.9, h->train_step), bc2 = 1.0 - std::pow(0.999, h->train_step);
+    p.lr_over_bc1 = (float)(lr / bc1);
+    p.inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
+    p.lr = (float)lr;
+    hipLaunchKernelGGL(k_train_apply, dim3((p.n + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), p);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
+int mzs_get_weights(mzs_handle* h, float* blob_out, size_t n_floats) {
+    if (!h || !blob_out) return fail(MZS_E_ARG, "null argument");
+    if (!h->have_weights) return fail(MZS_E_STATE, "mzs_set_weights has not been called");
+    if (n_floats != mzs_blob_layout(&h->cfg.dims).total) return fail(MZS_E_ARG, "wrong blob size");
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(blob_out, h->blob_dev, n_floats * sizeof(float), hipMemcpyDefault));
+    return MZS_OK;
+}
+
 }  // extern "C"
+

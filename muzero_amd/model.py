@@ -137,6 +137,7 @@ class Muzero:
         self.bin_method, self.bin_decomposition_number = bin_method, bin_decomposition_number
         self.is_RGB = False
         self._engine = None
+        self._trainer = None
         self._blob = None
         self.weights_version = 0
         if not load:
@@ -222,8 +223,41 @@ class Muzero:
         return pol.cpu().numpy(), (val if reanalyze else val[0])
 
     def train(self, batch):
-        raise NotImplementedError("the unroll-K training step is outside this round's scope "
-                                  "(SURVEY.md §8a T1-T7, secondary path)")
+        """muzero_model.py:791-811: one optimizer step on `batch` = (samples, importance-sampling
+        ratio, game positions) as ReplayBuffer.sample_batch returns it (replay_buffer.py:131-166).
+        Returns (new_priority: list of K arrays (B, 1), batch_game_position); appends
+        [loss_nn, value_0, policy_0, value_1, policy_1, reward_1, ...] to store_loss.
+        With torch.distributed initialised each rank passes its shard of the batch."""
+        from . import train as tr
+        if self.loss_type != "general":
+            raise NotImplementedError(f"loss_type={self.loss_type!r}: only the 'general' cross-entropy "
+                                      "losses every shipped config uses (muzero_model.py:350-361)")
+        obs, actions, tv, trw, tp, ratio, game_pos = tr.reshape_batch(
+            batch, self.observation_dimension, self.action_dimension, self.k_hypothetical_steps)
+        B = obs.shape[0]
+        if self._trainer is None or self._trainer.max_batch < B:
+            if self._trainer is not None:       # a bigger batch: new handle, keep step count / weights
+                self._blob = self._trainer.weights()
+                self._engine = None
+            eng = self._inference_engine()
+            old = self._trainer
+            self._trainer = tr.Trainer(eng, self.k_hypothetical_steps, B, self.opt, self.lr, self.sch,
+                                       self.epoch)
+            if old is not None:
+                raise NotImplementedError("growing the batch size after the first train() call would "
+                                          "drop the optimizer state; create the model with the "
+                                          "largest batch first")
+        t = self._trainer
+        t.count = self.count
+        prio = t.step(obs, actions, tv, trw, tp, ratio)
+        self.count = t.count
+        torch.cuda.synchronize(t.eng.device)
+        loss = t.loss.cpu().numpy()
+        self.store_loss.append([torch.tensor(loss[-1])] + [torch.tensor(x) for x in loss[:-1]])
+        self._blob = t.weights()
+        self.weights_version += 1
+        prio = prio.cpu().numpy()
+        return [prio[k].reshape(-1, 1) for k in range(prio.shape[0])], game_pos
 
     # -------------------------------------------------------------- checkpoints
     def _init_variables(self):

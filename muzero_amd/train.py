@@ -1,0 +1,147 @@
+"""Training step of the MLP MuZero model on the MI355X: host side of `Muzero.train`
+(/root/reference muzero_model.py:791-811).
+
+Host work (this file): reshape_batch (muzero_model.py:440-472), the learning-rate schedulers
+(muzero_model.py:423-433, stepped with `epoch=count`, :771) and the data-parallel exchange.
+Device work (muzero_amd/csrc/mzs_train.h through the C-ABI): forward, losses, backward,
+weight gradients, optimizer.
+
+Data parallelism: one process per GPU; every rank runs `mzs_train_grad` on its shard of the
+batch with `inv_global_batch = 1 / global batch size`, the flat fp32 gradient (12 734 floats
+for the CartPole MLP) is summed with ONE `all_reduce` (RCCL over xGMI under the "nccl"
+backend, gloo in the CPU tests) and every rank applies the same optimizer step, so the
+replicas stay bit-identical without a weight broadcast.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+
+OPTIMIZERS = {"adam": _lib.OPT_ADAM, "sgd": _lib.OPT_SGD}
+SCHEDULERS = (None, "none", "steplr", "cosineannealinglr", "cosineannealinglrwarmrestarts")
+
+
+def scheduled_lr(scheduler, base_lr, num_of_epoch, count):
+    """Learning rate the reference's optimizer holds when train() number `count` (0-based) runs.
+
+    The reference calls `scheduler.step(epoch=self.count)` AFTER `optimizer.step()` and before
+    `count += 1` (muzero_model.py:764-786), which sets the closed-form value for epoch = count;
+    so step 0 runs at the base rate and step i > 0 at closed_form(i - 1)."""
+    if scheduler in (None, "none") or count == 0:
+        return float(base_lr)
+    e = count - 1
+    if scheduler == "steplr":                      # StepLR(step_size=1, gamma=0.99)
+        return float(base_lr) * 0.99 ** e
+    if scheduler == "cosineannealinglr":           # CosineAnnealingLR(T_max=num_of_epoch), eta_min 0
+        return float(base_lr) * (1.0 + math.cos(math.pi * e / int(num_of_epoch))) / 2.0
+    if scheduler == "cosineannealinglrwarmrestarts":  # CosineAnnealingWarmRestarts(T_0=num_of_epoch)
+        t0 = int(num_of_epoch)
+        return float(base_lr) * (1.0 + math.cos(math.pi * (e % t0) / t0)) / 2.0
+    raise NotImplementedError(f"lr_scheduler={scheduler!r}: OneCycleLR also cycles Adam's beta1 per "
+                              "step, which the fused optimizer kernel does not model")
+
+
+def reshape_batch(batches, obs_dim, n_actions, unroll_steps):
+    """muzero_model.py:440-472 on numpy: (batch, importance_sampling_ratio, game_pos) ->
+    obs [B, obs], actions [K, B, A], target value / reward [K, B], target policy [K, B, A],
+    is_ratio [B] or None (a single-element ratio means "no importance weighting", :730)."""
+    batch, ratio, game_pos = batches
+    B, K = len(batch), int(unroll_steps)
+    obs = np.empty((B, obs_dim), np.float32)
+    actions = np.zeros((K, B, n_actions), np.float32)
+    tv = np.zeros((K, B), np.float32)
+    tr = np.zeros((K, B), np.float32)
+    tp = np.zeros((K, B, n_actions), np.float32)
+    for b, (o, acts, targets) in enumerate(batch):
+        o = o.detach().cpu().numpy() if torch.is_tensor(o) else np.asarray(o)
+        obs[b] = np.asarray(o, np.float32).reshape(-1)
+        if len(acts) != K or len(targets) != K:
+            raise ValueError(f"sample {b}: {len(acts)} actions / {len(targets)} targets, expected {K}")
+        for k in range(K):
+            actions[k, b] = np.asarray(acts[k], np.float32).reshape(-1)
+            tv[k, b] = targets[k][0]
+            tr[k, b] = targets[k][1]
+            tp[k, b] = np.asarray(targets[k][2], np.float32).reshape(-1)
+    ratio = np.asarray(ratio, np.float32).reshape(-1)
+    return obs, actions, tv, tr, tp, (None if ratio.size == 1 else ratio), game_pos
+
+
+def allreduce_gradient(grad, loss, group=None):
+    """The only collective of the training path: SUM the flat gradient bucket (and the small loss
+    vector) over the data-parallel ranks, in place.  No-op for one rank / no process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 1
+    dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
+    return dist.get_world_size(group)
+
+
+class Trainer:
+    """Owns the training state of one engine handle (one GPU)."""
+
+    def __init__(self, engine, unroll_steps, max_batch, optimizer="adam", learning_rate=1e-3,
+                 lr_scheduler=None, num_of_epoch=300):
+        if optimizer not in OPTIMIZERS:
+            raise ValueError(f"optimizer={optimizer!r}: 'adam' or 'sgd' (muzero_model.py:418-421)")
+        if lr_scheduler not in SCHEDULERS:
+            scheduled_lr(lr_scheduler, learning_rate, num_of_epoch, 1)   # raises with the reason
+        self.eng = engine
+        self.lib = engine.lib
+        self.K, self.max_batch = int(unroll_steps), int(max_batch)
+        self.opt, self.lr, self.sch, self.epoch = optimizer, float(learning_rate), lr_scheduler, num_of_epoch
+        self.count = 0
+        _lib.check(self.lib.mzs_train_create(engine.h, self.max_batch, self.K), "mzs_train_create")
+        dev, n = engine.device, engine.weight_count()
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.loss = torch.zeros(3 * self.K, dtype=torch.float32, device=dev)
+        self.priority = torch.zeros((self.K, self.max_batch), dtype=torch.float32, device=dev)
+
+    def current_lr(self):
+        return scheduled_lr(self.sch, self.lr, self.epoch, self.count)
+
+    def grad_step(self, obs, actions, tv, tr, tp, is_ratio=None, global_batch=None):
+        """Enqueue forward + losses + backward for this rank's shard; fills self.grad / self.loss /
+        self.priority[:, :B] (device tensors, no host sync)."""
+        e = self.eng
+        obs = e._dev(obs, torch.float32)
+        B = obs.shape[0]
+        if B > self.max_batch:
+            raise ValueError(f"batch {B} exceeds max_batch {self.max_batch}")
+        actions, tv, tr, tp = (e._dev(a, torch.float32) for a in (actions, tv, tr, tp))
+        assert actions.shape == (self.K, B, e.A) and tv.shape == (self.K, B) and tp.shape == (self.K, B, e.A)
+        isr = e._dev(is_ratio, torch.float32)
+        self._keep = (obs, actions, tv, tr, tp, isr)
+        prio = self.priority if B == self.max_batch else torch.zeros((self.K, B), dtype=torch.float32,
+                                                                     device=e.device)
+        p = lambda t: None if t is None else C.c_void_p(t.data_ptr())  # noqa: E731
+        _lib.check(self.lib.mzs_train_grad(e.h, B, p(obs), p(actions), p(tv), p(tr), p(tp), p(isr),
+                                           C.c_float(1.0 / float(global_batch or B)), p(self.grad),
+                                           p(self.loss), p(prio), e._stream()), "mzs_train_grad")
+        return prio
+
+    def apply(self):
+        e = self.eng
+        _lib.check(self.lib.mzs_train_apply(e.h, C.c_void_p(self.grad.data_ptr()), OPTIMIZERS[self.opt],
+                                            C.c_double(self.current_lr()), e._stream()), "mzs_train_apply")
+        self.count += 1
+
+    def step(self, obs, actions, tv, tr, tp, is_ratio=None, group=None):
+        """One data-parallel training step.  With torch.distributed initialised every rank passes its
+        own shard (equal sizes); gradients and loss terms are summed over ranks."""
+        import torch.distributed as dist
+        world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        B = np.shape(obs)[0] if not torch.is_tensor(obs) else obs.shape[0]
+        prio = self.grad_step(obs, actions, tv, tr, tp, is_ratio, global_batch=B * world)
+        allreduce_gradient(self.grad, self.loss, group)                      # one flat bucket
+        self.apply()
+        return prio
+
+    def weights(self):
+        n = self.eng.weight_count()
+        out = np.empty(n, np.float32)
+        _lib.check(self.lib.mzs_get_weights(self.eng.h, out.ctypes.data_as(C.c_void_p), n), "mzs_get_weights")
+        return out

@@ -23,6 +23,8 @@
 #ifndef MZ_ORACLE_H
 #define MZ_ORACLE_H
 
+#include <stddef.h>
+
 #include "../include/mzs_layout.h"
 
 #ifdef __cplusplus
@@ -83,6 +85,26 @@ float mzo_elu(float x);
 int mzo_search(const mzo_search_cfg* cfg, const float* blob, const mzo_table_model* tbl,
                const float* obs, const double* dirichlet, const double* noise,
                int64_t noise_stride, int32_t G, const mzo_search_out* out);
+
+/* ---- training step (oracle/mz_train_oracle.c; pinned by tests/golden/train_*.npz) ---- */
+typedef struct mzo_train_batch {
+    int32_t B, K;               /* samples in this shard, unroll length (k_hypothetical_steps)  */
+    const float* obs;           /* [B][obs_dim]                                                 */
+    const float* actions;       /* [K][B][A]  one-hot, or zeros for absorbing positions         */
+    const float* target_value;  /* [K][B]                                                       */
+    const float* target_reward; /* [K][B]                                                       */
+    const float* target_policy; /* [K][B][A]                                                    */
+    const float* is_ratio;      /* [B] importance-sampling ratio, NULL = none (uniform sampling) */
+    float inv_batch;            /* 1 / global batch size                                        */
+} mzo_train_batch;
+
+/* Muzero.train up to (not including) the optimizer step: grad [total blob floats] (blob order),
+ * loss_terms [3K-1] batch means of the raw terms in store_loss order, *total_loss = loss_nn,
+ * priority [K][B] = |h^-1(value_k) - target_value_k| (muzero_model.py:710-713). */
+int mzo_train_grad(const mzs_dims* d, const float* blob, const mzo_train_batch* bt, float* grad,
+                   float* loss_terms, double* total_loss, float* priority);
+void mzo_adam_step(float* w, float* m, float* v, const float* g, size_t n, int step, double lr);
+void mzo_sgd_step(float* w, float* buf, const float* g, size_t n, int step, double lr);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,10 @@ class SearchOut(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libmzoracle.so")
-    if force or not os.path.exists(so):
+    srcs = [os.path.join(_HERE, f) for f in ("mz_oracle.c", "mz_train_oracle.c", "mz_oracle.h")]
+    stale = os.path.exists(so) and all(os.path.exists(f) for f in srcs) and \
+        os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs)
+    if force or stale or not os.path.exists(so):
         subprocess.check_call(["make", "-C", _HERE, "libmzoracle.so"], stdout=subprocess.DEVNULL)
     return so
 
@@ -168,3 +171,53 @@ def search(d, blob, S, gamma, frac, pbc_table, obs=None, dirichlet=None, noise=N
     if rc != 0:
         raise RuntimeError(f"mzo_search failed: {rc}")
     return res
+
+
+# ------------------------------------------------------------------ training step
+class TrainBatch(C.Structure):
+    _fields_ = [("B", C.c_int32), ("K", C.c_int32), ("obs", C.c_void_p), ("actions", C.c_void_p),
+                ("target_value", C.c_void_p), ("target_reward", C.c_void_p),
+                ("target_policy", C.c_void_p), ("is_ratio", C.c_void_p), ("inv_batch", C.c_float)]
+
+
+def blob_size(d):
+    from muzero_amd.model import blob_layout
+    return sum(int(np.prod(shp)) for _, shp in
+               blob_layout(d.obs_dim, d.n_actions, d.state_dim, d.hidden_dim, d.n_mid_layers))
+
+
+def train_grad(d, blob, obs, actions, target_value, target_reward, target_policy, is_ratio=None,
+               global_batch=None):
+    """Forward + losses + backward of one training step on a batch (shard).  Returns
+    dict(grad [P], loss_terms [3K-1], total_loss, priority [K, B])."""
+    obs, actions = _f32(obs), _f32(actions)
+    tv, tr, tp = _f32(target_value), _f32(target_reward), _f32(target_policy)
+    K, B = tv.shape
+    isr = None if is_ratio is None else _f32(is_ratio)
+    bt = TrainBatch(B, K, _p(obs).value, _p(actions).value, _p(tv).value, _p(tr).value, _p(tp).value,
+                    None if isr is None else _p(isr).value, 1.0 / float(global_batch or B))
+    blob = _f32(blob)
+    n = blob_size(d)
+    assert blob.size == n
+    grad = np.zeros(n, np.float32)
+    terms = np.zeros(3 * K - 1, np.float32)
+    total = C.c_double(0.0)
+    prio = np.zeros((K, B), np.float32)
+    f = lib().mzo_train_grad
+    f.restype = C.c_int
+    rc = f(C.byref(d), _p(blob), C.byref(bt), _p(grad), _p(terms), C.byref(total), _p(prio))
+    if rc != 0:
+        raise RuntimeError(f"mzo_train_grad failed: {rc}")
+    return dict(grad=grad, loss_terms=terms, total_loss=total.value, priority=prio)
+
+
+def adam_step(w, m, v, g, step, lr):
+    f = lib().mzo_adam_step
+    f.restype = None
+    f(_p(w), _p(m), _p(v), _p(_f32(g)), C.c_size_t(w.size), C.c_int(step), C.c_double(lr))
+
+
+def sgd_step(w, buf, g, step, lr):
+    f = lib().mzo_sgd_step
+    f.restype = None
+    f(_p(w), _p(buf), _p(_f32(g)), C.c_size_t(w.size), C.c_int(step), C.c_double(lr))

@@ -1,0 +1,321 @@
+/*
+ * mz_train_oracle.c — CPU oracle of the unroll-K training step (test infrastructure, see
+ * mz_oracle.h).  Restates, for the MLP model family:
+ *   Muzero.compute_forward            muzero_model.py:609-647   (hidden-state gradient x0.5, :640)
+ *   Muzero.evaluate_loss              muzero_model.py:650-734   (zip() drops the (K+1)-th prediction,
+ *                                                                1/K gradient scale for k > 0 :657,:601)
+ *   Muzero.transform_with_support     muzero_model.py:536-563   (single-bin encoding, kept as is)
+ *   Loss_function.cross_entropy       neural_network_mlp_model.py:240-243 (softmax, + 1e-9)
+ *   l2                                neural_network_mlp_model.py:280-285 (zip() truncates to the
+ *                                                                shortest parameter list)
+ *   torch.optim.Adam / SGD(momentum)  muzero_model.py:418-421
+ * Pinned by tests/golden/train_*.npz (made from the reference by make_train_fixtures.py).
+ * Storage is fp32 like the reference; dot products accumulate in double, so torch-CPU and the
+ * GPU path both sit within fp32 rounding of it (tolerances in tests/test_train_*.py).
+ */
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "mz_oracle.h"
+#include "../include/mzs_numeric.h"
+
+typedef struct net {
+    int nin, ld, H, L;
+    const float *Win, *bin, *Wmid, *bmid;
+    float *gWin, *gbin, *gWmid, *gbmid;
+} net;
+
+static float elu_f(float z) { return z > 0.0f ? z : (float)expm1((double)z); }
+
+static void lin(const float* W, const float* b, const float* x, int nout, int nin, int ld, float* y) {
+    for (int j = 0; j < nout; ++j) {
+        double acc = b[j];
+        for (int k = 0; k < nin; ++k) acc += (double)W[(size_t)j * ld + k] * x[k];
+        y[j] = (float)acc;
+    }
+}
+
+/* T[(L+1)][H]: activations after every ELU */
+static void net_forward(const net* n, const float* x, float* T) {
+    lin(n->Win, n->bin, x, n->H, n->nin, n->ld, T);
+    for (int j = 0; j < n->H; ++j) T[j] = elu_f(T[j]);
+    for (int l = 0; l < n->L; ++l) {
+        float* t1 = T + (size_t)(l + 1) * n->H;
+        lin(n->Wmid, n->bmid, T + (size_t)l * n->H, n->H, n->H, n->H, t1);
+        for (int j = 0; j < n->H; ++j) t1[j] = elu_f(t1[j]);
+    }
+}
+
+/* y += W^T d */
+static void lin_back_input(const float* W, const float* d, int nout, int nin, int ld, float* gx) {
+    for (int k = 0; k < nin; ++k) {
+        double acc = 0.0;
+        for (int j = 0; j < nout; ++j) acc += (double)W[(size_t)j * ld + k] * d[j];
+        gx[k] = (float)acc;
+    }
+}
+
+static void lin_back_weight(float* gW, float* gb, const float* d, const float* x, int nout, int nin,
+                            int ld) {
+    for (int j = 0; j < nout; ++j) {
+        for (int k = 0; k < nin; ++k) gW[(size_t)j * ld + k] += d[j] * x[k];
+        gb[j] += d[j];
+    }
+}
+
+/* gT: gradient w.r.t. the last trunk activation (clobbered); gx: gradient w.r.t. the input */
+static void net_backward(const net* n, const float* x, const float* T, float* gT, float* gx,
+                         float* tmp) {
+    for (int l = n->L; l >= 1; --l) {
+        const float* t = T + (size_t)l * n->H;
+        for (int j = 0; j < n->H; ++j) gT[j] *= t[j] > 0.0f ? 1.0f : t[j] + 1.0f;
+        lin_back_weight(n->gWmid, n->gbmid, gT, T + (size_t)(l - 1) * n->H, n->H, n->H, n->H);
+        lin_back_input(n->Wmid, gT, n->H, n->H, n->H, tmp);
+        memcpy(gT, tmp, sizeof(float) * (size_t)n->H);
+    }
+    for (int j = 0; j < n->H; ++j) gT[j] *= T[j] > 0.0f ? 1.0f : T[j] + 1.0f;
+    lin_back_weight(n->gWin, n->gbin, gT, x, n->H, n->nin, n->ld);
+    if (gx) lin_back_input(n->Win, gT, n->H, n->nin, n->ld, gx);
+}
+
+typedef struct scale_rec {
+    int imin, imax;
+    float sc;
+} scale_rec;
+
+/* scale_to_bound_action forward (neural_network_mlp_model.py:135-143); first index on ties */
+static void scale_forward(const float* z, int n, float* h, scale_rec* r) {
+    r->imin = r->imax = 0;
+    for (int i = 1; i < n; ++i) {
+        if (z[i] < z[r->imin]) r->imin = i;
+        if (z[i] > z[r->imax]) r->imax = i;
+    }
+    float sc = z[r->imax] - z[r->imin];
+    if (sc < 1e-5f) sc = sc + 1e-5f;
+    r->sc = sc;
+    for (int i = 0; i < n; ++i) h[i] = (z[i] - z[r->imin]) / sc;
+}
+
+/* g: dL/dh  ->  gz: dL/dz */
+static void scale_backward(const float* g, const float* h, int n, const scale_rec* r, float* gz) {
+    double gsum = 0.0, ghs = 0.0;
+    for (int i = 0; i < n; ++i) {
+        gsum += g[i];
+        ghs += (double)g[i] * h[i];
+    }
+    const double dsc = -ghs / r->sc;            /* dL/d(scale)            */
+    const double dmn = -gsum / r->sc - dsc;     /* dL/d(min)  (scale = max - min) */
+    for (int i = 0; i < n; ++i) gz[i] = g[i] / r->sc;
+    gz[r->imin] += (float)dmn;
+    gz[r->imax] += (float)dsc;
+}
+
+/* transform_with_support (muzero_model.py:536-563): one (index, weight) pair */
+static void support_target(float x, int S, int* idx, float* weight) {
+    const int sd = S / 2;
+    const int rem = (int)(2.0 * ((double)S / 2.0 - (double)sd));
+    float ax = fabsf(x);
+    float sg0 = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
+    float t = sg0 * (sqrtf(ax + 1.0f) - 1.0f) + 0.001f * x;
+    if (t < (float)-sd) t = (float)-sd;
+    if (t > (float)(sd + rem)) t = (float)(sd + rem);
+    float sg = t > 0.0f ? 1.0f : (t < 0.0f ? -1.0f : 0.0f);
+    float fl = floorf(t), w = (ceilf(t) - t) * sg;
+    long i = (long)(fl + (float)sd + 1.0f);
+    if (i < -(S - 1)) i = -(S - 1);
+    if (i > S - 1) i = S - 1;
+    *idx = (int)i;
+    *weight = w;
+}
+
+/* cross entropy of softmax(z) + 1e-9 against p; gz += upstream * dloss/dz; returns the loss */
+static float ce_loss(const float* z, int n, const float* p, float upstream, float* gz, float* s) {
+    float m = z[0];
+    for (int i = 1; i < n; ++i) m = z[i] > m ? z[i] : m;
+    double Z = 0.0;
+    for (int i = 0; i < n; ++i) {
+        s[i] = expf(z[i] - m);
+        Z += s[i];
+    }
+    double loss = 0.0, dot = 0.0;
+    for (int i = 0; i < n; ++i) {
+        s[i] = (float)(s[i] / Z);
+        const float q = s[i] + 1e-9f;
+        loss += -(double)p[i] * log((double)q);
+        dot += (double)(-p[i] / q) * s[i];
+    }
+    if (gz)
+        for (int i = 0; i < n; ++i) {
+            const float q = s[i] + 1e-9f;
+            gz[i] += upstream * s[i] * (float)((double)(-p[i] / q) - dot);
+        }
+    return (float)loss;
+}
+
+int mzo_train_grad(const mzs_dims* d, const float* blob, const mzo_train_batch* bt, float* grad,
+                   float* loss_terms, double* total_loss, float* priority) {
+    const int obs = d->obs_dim, A = d->n_actions, S = d->state_dim, H = d->hidden_dim,
+              L = d->n_mid_layers, K = bt->K, B = bt->B;
+    if (K < 1 || B < 1) return -1;
+    const mzs_blob_offsets o = mzs_blob_layout(d);
+    memset(grad, 0, sizeof(float) * o.total);
+    const int n_terms = 3 * K - 1;
+    for (int i = 0; i < n_terms; ++i) loss_terms[i] = 0.0f;
+    net R = {obs, obs, H, L, blob + o.r_in_w, blob + o.r_in_b, blob + o.r_mid_w, blob + o.r_mid_b,
+             grad + o.r_in_w, grad + o.r_in_b, grad + o.r_mid_w, grad + o.r_mid_b};
+    net D = {S + A, S + A, H, L, blob + o.d_in_w, blob + o.d_in_b, blob + o.d_mid_w, blob + o.d_mid_b,
+             grad + o.d_in_w, grad + o.d_in_b, grad + o.d_mid_w, grad + o.d_mid_b};
+    net P = {S, S, H, L, blob + o.p_in_w, blob + o.p_in_b, blob + o.p_mid_w, blob + o.p_mid_b,
+             grad + o.p_in_w, grad + o.p_in_b, grad + o.p_mid_w, grad + o.p_mid_b};
+    const size_t TH = (size_t)(L + 1) * H;
+    float* h = (float*)malloc(sizeof(float) * (size_t)K * S);          /* hidden states h_0..h_{K-1} */
+    float* zs = (float*)malloc(sizeof(float) * (size_t)K * S);         /* pre-scale rows             */
+    scale_rec* sr = (scale_rec*)malloc(sizeof(scale_rec) * (size_t)K);
+    float* TR = (float*)malloc(sizeof(float) * TH);
+    float* TP = (float*)malloc(sizeof(float) * TH * K);
+    float* TD = (float*)malloc(sizeof(float) * TH * K);
+    float* xD = (float*)malloc(sizeof(float) * (size_t)K * (S + A));
+    float* pol = (float*)malloc(sizeof(float) * (size_t)K * A);
+    float* val = (float*)malloc(sizeof(float) * (size_t)K * S);
+    float* rew = (float*)malloc(sizeof(float) * (size_t)K * S);        /* rew[k] = reward logits of step k (k >= 1) */
+    float* gT = (float*)malloc(sizeof(float) * (size_t)H * 3);
+    float *tmp = gT + H, *gT2 = gT + 2 * H;
+    int nmax = S + A > H ? S + A : H;
+    float* gz = (float*)malloc(sizeof(float) * (size_t)nmax * 6);
+    float *gz2 = gz + nmax, *gh = gz + 2 * nmax, *ghn = gz + 3 * nmax, *sm = gz + 4 * nmax,
+          *ptar = gz + 5 * nmax;
+    double total = 0.0, wsum = 0.0;
+
+    for (int b = 0; b < B; ++b) {
+        const float w = (bt->is_ratio ? bt->is_ratio[b] : 1.0f) * bt->inv_batch;
+        wsum += w;
+        const float* ob = bt->obs + (size_t)b * obs;
+        /* ---------------- forward (muzero_model.py:609-647) */
+        net_forward(&R, ob, TR);
+        lin(blob + o.r_out_w, blob + o.r_out_b, TR + (size_t)L * H, S, H, H, zs);
+        scale_forward(zs, S, h, &sr[0]);
+        for (int k = 0; k < K; ++k) {
+            float* tp = TP + TH * k;
+            net_forward(&P, h + (size_t)k * S, tp);
+            lin(blob + o.p_pol_w, blob + o.p_pol_b, tp + (size_t)L * H, A, H, H, pol + (size_t)k * A);
+            lin(blob + o.p_val_w, blob + o.p_val_b, tp + (size_t)L * H, S, H, H, val + (size_t)k * S);
+            if (k + 1 < K) {
+                float* x = xD + (size_t)k * (S + A);
+                memcpy(x, h + (size_t)k * S, sizeof(float) * (size_t)S);
+                memcpy(x + S, bt->actions + ((size_t)k * B + b) * A, sizeof(float) * (size_t)A);
+                float* td = TD + TH * k;
+                net_forward(&D, x, td);
+                lin(blob + o.d_rew_w, blob + o.d_rew_b, td + (size_t)L * H, S, H, H,
+                    rew + (size_t)(k + 1) * S);
+                lin(blob + o.d_st_w, blob + o.d_st_b, td + (size_t)L * H, S, H, H,
+                    zs + (size_t)(k + 1) * S);
+                scale_forward(zs + (size_t)(k + 1) * S, S, h + (size_t)(k + 1) * S, &sr[k + 1]);
+            }
+        }
+        /* ---------------- losses + backward (muzero_model.py:650-734) */
+        double sample_loss = 0.0;
+        for (int i = 0; i < S; ++i) ghn[i] = 0.0f; /* dL/dh_{k} arriving from dynamics step k */
+        for (int k = K - 1; k >= 0; --k) {
+            const float gs = (k > 0 ? 1.0f / (float)K : 1.0f) * w;
+            const int t0 = k == 0 ? 0 : 3 * k - 1; /* term order: v0 p0 | v1 p1 r1 | ... */
+            const float* tp = TP + TH * k;
+            /* value */
+            int idx;
+            float wt;
+            support_target(bt->target_value[(size_t)k * B + b], S, &idx, &wt);
+            for (int i = 0; i < S; ++i) ptar[i] = 0.0f;
+            ptar[idx] = wt;
+            for (int i = 0; i < S; ++i) gz[i] = 0.0f;
+            float lv = ce_loss(val + (size_t)k * S, S, ptar, gs, gz, sm);
+            /* policy */
+            for (int i = 0; i < A; ++i) gz2[i] = 0.0f;
+            float lp = ce_loss(pol + (size_t)k * A, A, bt->target_policy + ((size_t)k * B + b) * A, gs,
+                               gz2, sm);
+            loss_terms[t0] += lv * bt->inv_batch;
+            loss_terms[t0 + 1] += lp * bt->inv_batch;
+            sample_loss += (double)lv + lp;
+            priority[(size_t)k * B + b] =
+                fabsf(mzo_support_to_scalar(val + (size_t)k * S, S) - bt->target_value[(size_t)k * B + b]);
+            /* prediction heads -> trunk */
+            lin_back_weight(grad + o.p_val_w, grad + o.p_val_b, gz, tp + (size_t)L * H, S, H, H);
+            lin_back_weight(grad + o.p_pol_w, grad + o.p_pol_b, gz2, tp + (size_t)L * H, A, H, H);
+            lin_back_input(blob + o.p_val_w, gz, S, H, H, gT);
+            lin_back_input(blob + o.p_pol_w, gz2, A, H, H, gT2);
+            for (int j = 0; j < H; ++j) gT[j] += gT2[j];
+            net_backward(&P, h + (size_t)k * S, tp, gT, gh, tmp);
+            for (int i = 0; i < S; ++i) gh[i] += ghn[i];
+            if (k > 0) {
+                for (int i = 0; i < S; ++i) gh[i] *= 0.5f; /* register_hook, muzero_model.py:640 */
+                scale_backward(gh, h + (size_t)k * S, S, &sr[k], gz);
+                /* reward of step k (from dynamics step k-1) */
+                support_target(bt->target_reward[(size_t)k * B + b], S, &idx, &wt);
+                for (int i = 0; i < S; ++i) ptar[i] = 0.0f;
+                ptar[idx] = wt;
+                for (int i = 0; i < S; ++i) gz2[i] = 0.0f;
+                float lr = ce_loss(rew + (size_t)k * S, S, ptar, gs, gz2, sm);
+                loss_terms[t0 + 2] += lr * bt->inv_batch;
+                sample_loss += lr;
+                const float* td = TD + TH * (k - 1);
+                lin_back_weight(grad + o.d_st_w, grad + o.d_st_b, gz, td + (size_t)L * H, S, H, H);
+                lin_back_weight(grad + o.d_rew_w, grad + o.d_rew_b, gz2, td + (size_t)L * H, S, H, H);
+                lin_back_input(blob + o.d_st_w, gz, S, H, H, gT);
+                lin_back_input(blob + o.d_rew_w, gz2, S, H, H, gT2);
+                for (int j = 0; j < H; ++j) gT[j] += gT2[j];
+                net_backward(&D, xD + (size_t)(k - 1) * (S + A), td, gT, gz, tmp);
+                for (int i = 0; i < S; ++i) ghn[i] = gz[i]; /* the action columns get no gradient use */
+            } else {
+                scale_backward(gh, h, S, &sr[0], gz);
+                lin_back_weight(grad + o.r_out_w, grad + o.r_out_b, gz, TR + (size_t)L * H, S, H, H);
+                lin_back_input(blob + o.r_out_w, gz, S, H, H, gT);
+                net_backward(&R, ob, TR, gT, NULL, tmp);
+            }
+        }
+        total += (double)w * sample_loss;
+    }
+    /* l2 (neural_network_mlp_model.py:280-285): zip over the three parameter lists stops at the
+     * shortest (the representation's), so the dynamics' next-state head and the prediction's value
+     * head are left out */
+    {
+        const size_t segs[][2] = {
+            {o.r_in_w, (size_t)H * obs}, {o.r_in_b, (size_t)H}, {o.r_out_w, (size_t)S * H}, {o.r_out_b, (size_t)S},
+            {o.d_in_w, (size_t)H * (S + A)}, {o.d_in_b, (size_t)H}, {o.d_rew_w, (size_t)S * H}, {o.d_rew_b, (size_t)S},
+            {o.p_in_w, (size_t)H * S}, {o.p_in_b, (size_t)H}, {o.p_pol_w, (size_t)A * H}, {o.p_pol_b, (size_t)A},
+            {o.r_mid_w, (size_t)H * H}, {o.r_mid_b, (size_t)H}, {o.d_mid_w, (size_t)H * H}, {o.d_mid_b, (size_t)H},
+            {o.p_mid_w, (size_t)H * H}, {o.p_mid_b, (size_t)H}};
+        const int nseg = L > 0 ? 18 : 12;
+        double sq = 0.0;
+        for (int s = 0; s < nseg; ++s)
+            for (size_t i = 0; i < segs[s][1]; ++i) {
+                const float wv = blob[segs[s][0] + i];
+                sq += (double)wv * wv;
+                grad[segs[s][0] + i] += (float)(2.0 * 1e-4 * wsum) * wv;
+            }
+        total += wsum * 1e-4 * sq;
+    }
+    *total_loss = total;
+    free(h), free(zs), free(sr), free(TR), free(TP), free(TD), free(xD), free(pol), free(val), free(rew);
+    free(gT), free(gz);
+    return 0;
+}
+
+/* torch.optim.Adam (betas 0.9 / 0.999, eps 1e-8, no weight decay) — step t >= 1 */
+void mzo_adam_step(float* w, float* m, float* v, const float* g, size_t n, int step, double lr) {
+    const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+    const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
+    const double step_size = lr / bc1, bc2s = sqrt(bc2);
+    for (size_t i = 0; i < n; ++i) {
+        m[i] = m[i] + (g[i] - m[i]) * (float)(1.0 - b1);
+        v[i] = v[i] * (float)b2 + (float)(1.0 - b2) * g[i] * g[i];
+        const float denom = (float)(sqrtf(v[i]) / bc2s) + (float)eps;
+        w[i] = w[i] - (float)step_size * (m[i] / denom);
+    }
+}
+
+/* torch.optim.SGD(momentum = 0.9): buf = g on the first step */
+void mzo_sgd_step(float* w, float* buf, const float* g, size_t n, int step, double lr) {
+    for (size_t i = 0; i < n; ++i) {
+        buf[i] = step == 1 ? g[i] : 0.9f * buf[i] + g[i];
+        w[i] = w[i] - (float)lr * buf[i];
+    }
+}

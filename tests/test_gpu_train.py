@@ -1,0 +1,121 @@
+"""GPU parity of the training step (HIP kernels through the C-ABI) against the CPU oracle and
+the reference's own Muzero.train fixtures.  fp32 tolerances (north_star: 1e-5 relative)."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from test_train_oracle import GRAD_REL, LOSS_REL, TRAIN_FIXTURES, check_against_fixture, step_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def make_trainer(fx):
+    from muzero_amd.engine import SearchEngine
+    from muzero_amd.train import Trainer
+    dims = tuple(int(x) for x in fx["dims"])
+    sch = str(fx["scheduler"])
+    eng = SearchEngine(dims, max_games=1, max_simulations=0)
+    eng.set_weights(fx["blob0"])
+    tr = Trainer(eng, int(fx["K"]), int(fx["B"]), str(fx["optimizer"]), float(fx["lr"]),
+                 None if sch == "none" else sch, int(fx["epoch"]))
+    return eng, tr
+
+
+def gpu_out(tr, B):
+    import torch
+    torch.cuda.synchronize()
+    loss = tr.loss.cpu().numpy()
+    return dict(grad=tr.grad.cpu().numpy(), loss_terms=loss[:-1], total_loss=float(loss[-1]),
+                priority=tr.priority[:, :B].cpu().numpy())
+
+
+@pytest.mark.parametrize("fname", TRAIN_FIXTURES)
+def test_train_step_vs_oracle_and_reference(fname):
+    from oracle import mz_oracle as mzo
+    fx = load_golden(fname)
+    d = mzo.dims(*fx["dims"])
+    eng, tr = make_trainer(fx)
+    B = int(fx["B"])
+    for s in range(int(fx["n_steps"])):
+        inp = step_inputs(fx, s)
+        blob_before = tr.weights()
+        lr = tr.current_lr()
+        tr.grad_step(inp["obs"], inp["actions"], inp["target_value"], inp["target_reward"],
+                     inp["target_policy"], inp["is_ratio"])
+        got = gpu_out(tr, B)
+        ref = mzo.train_grad(d, blob_before, **inp)
+        assert abs(got["total_loss"] - ref["total_loss"]) <= LOSS_REL * abs(ref["total_loss"])
+        assert np.all(np.abs(got["loss_terms"] - ref["loss_terms"]) <= LOSS_REL * np.abs(ref["loss_terms"]) + 1e-7)
+        assert np.abs(got["grad"] - ref["grad"]).max() <= GRAD_REL * np.abs(ref["grad"]).max()
+        assert np.abs(got["priority"] - ref["priority"]).max() <= 1e-5 * (1 + np.abs(ref["priority"]).max())
+        tr.apply()
+        blob_after = tr.weights()
+        if s == 0:
+            check_against_fixture(fx, 0, got, blob_after, lr)      # the reference itself (same weights)
+        # optimizer kernel vs the oracle's optimizer on the same gradient
+        m = getattr(test_train_step_vs_oracle_and_reference, "_m", None)
+        if s == 0:
+            m, v = np.zeros_like(blob_before), np.zeros_like(blob_before)
+        else:
+            m, v = test_train_step_vs_oracle_and_reference._m, test_train_step_vs_oracle_and_reference._v
+        w = blob_before.copy()
+        if str(fx["optimizer"]) == "adam":
+            mzo.adam_step(w, m, v, got["grad"], s + 1, lr)
+        else:
+            mzo.sgd_step(w, m, got["grad"], s + 1, lr)
+        test_train_step_vs_oracle_and_reference._m, test_train_step_vs_oracle_and_reference._v = m, v
+        assert np.abs(blob_after - w).max() <= 1e-6 + 1e-5 * lr
+    eng.close()
+
+
+def test_training_updates_what_the_search_reads():
+    """After mzs_train_apply the inference kernels use the new weights (the transposed store is
+    refreshed on the device): inference on the trainer's engine == oracle inference with the
+    read-back blob, bit for bit."""
+    from oracle import mz_oracle as mzo
+    fx = load_golden("train_tag123_K5_B128.npz")
+    d = mzo.dims(*fx["dims"])
+    eng, tr = make_trainer(fx)
+    inp = step_inputs(fx, 0)
+    tr.step(inp["obs"], inp["actions"], inp["target_value"], inp["target_reward"], inp["target_policy"],
+            inp["is_ratio"])
+    blob = tr.weights()
+    assert not np.array_equal(blob, fx["blob0"])
+    hid, pol, val = [t.cpu().numpy() for t in eng.initial_inference(inp["obs"])]
+    oh, op, ov = mzo.initial_inference(d, blob, inp["obs"])
+    assert np.array_equal(hid.view(np.uint32), oh.view(np.uint32))
+    assert np.array_equal(pol.view(np.uint32), op.view(np.uint32))
+    assert np.array_equal(val.view(np.uint32), ov.view(np.uint32))
+    eng.close()
+
+
+def test_muzero_train_drop_in():
+    """Muzero.train with the reference's batch format: losses, priorities and weights after two
+    steps against the reference fixture (Adam + cosine annealing, unroll 5, batch 128)."""
+    import torch
+    from muzero_amd.model import Muzero
+    fx = load_golden("train_tag123_K5_B128.npz")
+    mz = Muzero(model_structure="mlp_model", observation_space_dimensions=4,
+                action_space_dimensions=2, state_space_dimensions=31, hidden_layer_dimensions=64,
+                number_of_hidden_layer=0, k_hypothetical_steps=5, learning_rate=0.01, optimizer="adam",
+                lr_scheduler="cosineannealinglr", num_of_epoch=10000)
+    mz.set_weights(fx["blob0"])
+    for s in range(2):
+        K, B, A = fx[f"s{s}_actions"].shape
+        batch = []
+        for b in range(B):
+            acts = [fx[f"s{s}_actions"][k, b] for k in range(K)]
+            tg = [[float(fx[f"s{s}_target_value"][k, b]), float(fx[f"s{s}_target_reward"][k, b]),
+                   fx[f"s{s}_target_policy"][k, b]] for k in range(K)]
+            batch.append((torch.tensor(fx[f"s{s}_obs"][b:b + 1]), acts, tg))
+        pos = np.stack([np.arange(B), np.arange(B)], axis=1)
+        prio, gp = mz.train((batch, fx[f"s{s}_is_ratio"], pos))
+        assert gp is pos and len(prio) == K and prio[0].shape == (B, 1)
+        L = fx[f"s{s}_losses"]
+        got = np.array([float(x) for x in mz.store_loss[-1]])
+        if s == 0:
+            assert np.all(np.abs(got - L) <= 1e-5 * np.abs(L) + 1e-7)
+        else:                      # second step starts from slightly different weights (Adam step 1)
+            assert np.all(np.abs(got - L) <= 2e-3 * np.abs(L) + 1e-4)
+        assert np.abs(mz.weights_blob() - fx[f"s{s}_blob"]).max() <= (s + 1) * 2e-3 * 0.01 + 1e-6
+    assert mz.count == 2

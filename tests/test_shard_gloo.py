@@ -65,3 +65,50 @@ def test_game_range_partitions():
     from muzero_amd import shard
     allg = np.concatenate([shard.game_range(r, 4096) for r in range(8)])
     assert np.array_equal(allg, np.arange(8 * 4096))
+
+
+TRAIN_WORKER = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["MZ_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MZ_ROOT"], "tests"))
+from muzero_amd import shard, train
+from oracle import mz_oracle as mzo
+from conftest import load_golden
+rank, world = shard.init("gloo")
+fx = load_golden("train_tag123_K5_B128.npz")
+d = mzo.dims(*fx["dims"])
+B = fx["s0_obs"].shape[0]; n = B // world; sl = slice(rank * n, (rank + 1) * n)
+out = mzo.train_grad(d, fx["blob0"], fx["s0_obs"][sl], fx["s0_actions"][:, sl], fx["s0_target_value"][:, sl],
+                     fx["s0_target_reward"][:, sl], fx["s0_target_policy"][:, sl],
+                     fx["s0_is_ratio"][sl].astype(np.float32), global_batch=B)
+grad = torch.from_numpy(out["grad"]); loss = torch.from_numpy(np.append(out["loss_terms"], np.float32(out["total_loss"])))
+assert train.allreduce_gradient(grad, loss) == world
+blob = fx["blob0"].copy(); m = np.zeros_like(blob); v = np.zeros_like(blob)
+mzo.adam_step(blob, m, v, grad.numpy(), 1, train.scheduled_lr("cosineannealinglr", 0.01, 10000, 0))
+np.savez(os.environ["MZ_OUT"] + f".{rank}.npz", blob=blob, grad=grad.numpy(), loss=loss.numpy())
+import torch.distributed as dist
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_training_step_two_ranks(tmp_path):
+    """Each rank: gradients of its half of the batch, ONE all-reduce of the flat bucket, the same
+    optimizer step -> both replicas hold the weights of the single-rank step (= the reference's)."""
+    from conftest import load_golden
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "dp")
+    script = tmp_path / "train_worker.py"
+    script.write_text(TRAIN_WORKER)
+    env = dict(os.environ, MZ_ROOT=ROOT, MZ_OUT=out, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    subprocess.run(cmd, env=env, check=True, timeout=300, capture_output=True)
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    assert np.array_equal(r0["blob"], r1["blob"]) and np.array_equal(r0["grad"], r1["grad"])
+    fx = load_golden("train_tag123_K5_B128.npz")
+    g = fx["s0_grad"]
+    assert np.abs(r0["grad"] - g).max() <= 1e-5 * np.abs(g).max()
+    assert abs(r0["loss"][-1] - fx["s0_losses"][0]) <= 1e-5 * fx["s0_losses"][0]
+    assert np.abs(r0["blob"] - fx["s0_blob"]).max() <= 2e-3 * 0.01 + 1e-6
