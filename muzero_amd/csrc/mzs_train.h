@@ -311,36 +311,59 @@ __global__ void __launch_bounds__(64) k_train_sample(const TrainParams p) {
     for (int i = lane; i < t.copy_n; i += kWave) dst[i] = T[i];
 }
 
-/* One thread per blob element: gradient = sum over samples and uses of delta[n] * x[k] (+ l2);
- * the last block reduces the loss terms. */
-__global__ void __launch_bounds__(256) k_train_wgrad(const TrainParams p, int n_grad_blocks) {
+constexpr int kWgradChunk = 8; /* samples per partial sum */
+
+/* Weight gradients, pass 1: thread (blob element i, sample chunk c) = sum over the chunk's
+ * samples and every use of the tensor of delta[n] * x[k]  ->  partial[c][i].  Fixed order, no
+ * atomics.  (blockIdx.y = chunk) */
+__global__ void __launch_bounds__(256) k_train_wgrad_partial(const TrainParams p, double* partial) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= p.n_params) return;
+    int ti = 0, n = 0, kk = -1;
+    for (int q = 0; q < kTrainTensors; ++q) {
+        const TensorDesc& d = p.td[q];
+        const int nw = d.n_out * d.n_in;
+        if (i >= d.w_off && i < d.w_off + nw) {
+            ti = q, n = (i - d.w_off) / d.n_in, kk = (i - d.w_off) % d.n_in;
+        } else if (i >= d.b_off && i < d.b_off + d.n_out) {
+            ti = q, n = i - d.b_off, kk = -1;
+        }
+    }
+    const TensorDesc d = p.td[ti];
+    const int b0 = blockIdx.y * kWgradChunk, b1 = min(b0 + kWgradChunk, p.B);
+    double acc = 0.0;
+    for (int b = b0; b < b1; ++b) {
+        const float* tape = p.tape + (size_t)b * p.tl.copy_n;
+        for (int u = 0; u < d.outer_n; ++u)
+            for (int v = 0; v < d.inner_n; ++v) {
+                const float dl = tape[d.d_off + u * d.outer_stride + v * d.inner_sd + n];
+                const float x = kk < 0 ? 1.0f : tape[d.x_off + u * d.outer_stride + v * d.inner_sx + kk];
+                acc += (double)dl * (double)x;
+            }
+    }
+    partial[(size_t)blockIdx.y * p.n_params + i] = acc;
+}
+
+/* pass 2: sum the chunk partials in order (+ l2); the last block reduces the loss terms */
+__global__ void __launch_bounds__(256) k_train_wgrad(const TrainParams p, const double* partial,
+                                                     int n_chunks, int n_grad_blocks) {
     const int K = p.K, B = p.B, n_terms = 3 * K - 1;
     if ((int)blockIdx.x < n_grad_blocks) {
         const int i = blockIdx.x * blockDim.x + threadIdx.x;
         if (i >= p.n_params) return;
-        int ti = 0, n = 0, kk = -1;
+        double acc = 0.0;
+        for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * p.n_params + i];
+        int l2 = 0;
         for (int q = 0; q < kTrainTensors; ++q) {
             const TensorDesc& d = p.td[q];
-            const int nw = d.n_out * d.n_in;
-            if (i >= d.w_off && i < d.w_off + nw) {
-                ti = q, n = (i - d.w_off) / d.n_in, kk = (i - d.w_off) % d.n_in;
-            } else if (i >= d.b_off && i < d.b_off + d.n_out) {
-                ti = q, n = i - d.b_off, kk = -1;
-            }
+            if ((i >= d.w_off && i < d.w_off + d.n_out * d.n_in) || (i >= d.b_off && i < d.b_off + d.n_out))
+                l2 = d.l2;
         }
-        const TensorDesc d = p.td[ti];
-        double acc = 0.0, wsum = 0.0;
-        for (int b = 0; b < B; ++b) {
-            const float* tape = p.tape + (size_t)b * p.tl.copy_n;
-            wsum += (double)((p.is_ratio ? p.is_ratio[b] : 1.0f) * p.inv_batch);
-            for (int u = 0; u < d.outer_n; ++u)
-                for (int v = 0; v < d.inner_n; ++v) {
-                    const float dl = tape[d.d_off + u * d.outer_stride + v * d.inner_sd + n];
-                    const float x = kk < 0 ? 1.0f : tape[d.x_off + u * d.outer_stride + v * d.inner_sx + kk];
-                    acc += (double)dl * (double)x;
-                }
+        if (l2) {
+            double wsum = 0.0;
+            for (int b = 0; b < B; ++b) wsum += (double)((p.is_ratio ? p.is_ratio[b] : 1.0f) * p.inv_batch);
+            acc += 2.0 * 1e-4 * wsum * (double)p.blob[i];
         }
-        if (d.l2) acc += 2.0 * 1e-4 * wsum * (double)p.blob[i];
         p.grad[i] = (float)acc;
         return;
     }

@@ -510,6 +510,7 @@ struct mzs_handle {
     float* loss_buf_dev = nullptr;
     float* adam_m_dev = nullptr;
     float* adam_v_dev = nullptr;
+    double* wgrad_partial_dev = nullptr;
     size_t w_floats = 0;
     bool have_weights = false;
     int n_nodes_max = 0;
@@ -1099,6 +1100,7 @@ int mzs_train_create(mzs_handle* h, int32_t max_batch, int32_t unroll_steps) {
     int rc;
     if ((rc = dev_alloc(h, &h->tape_dev, (size_t)max_batch * t.copy_n)) ||
         (rc = dev_alloc(h, &h->loss_buf_dev, (size_t)max_batch * (3 * unroll_steps - 1))) ||
+        (rc = dev_alloc(h, &h->wgrad_partial_dev, (size_t)((max_batch + kWgradChunk - 1) / kWgradChunk) * n)) ||
         (rc = dev_alloc(h, &h->adam_m_dev, n)) || (rc = dev_alloc(h, &h->adam_v_dev, n)))
         return rc;
     h->tape_layout = t;
@@ -1150,7 +1152,12 @@ int mzs_train_grad(mzs_handle* h, int32_t batch, const float* obs_dev, const flo
     hipLaunchKernelGGL(k_train_sample, dim3(batch), dim3(kWave), shmem, st, p);
     HIP_TRY(hipGetLastError());
     const int n_grad_blocks = (p.n_params + 255) / 256;
-    hipLaunchKernelGGL(k_train_wgrad, dim3(n_grad_blocks + 1), dim3(256), 0, st, p, n_grad_blocks);
+    const int n_chunks = (batch + kWgradChunk - 1) / kWgradChunk;
+    hipLaunchKernelGGL(k_train_wgrad_partial, dim3(n_grad_blocks, n_chunks), dim3(256), 0, st, p,
+                       h->wgrad_partial_dev);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_train_wgrad, dim3(n_grad_blocks + 1), dim3(256), 0, st, p,
+                       (const double*)h->wgrad_partial_dev, n_chunks, n_grad_blocks);
     HIP_TRY(hipGetLastError());
     return MZS_OK;
 }
