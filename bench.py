@@ -164,15 +164,30 @@ def main():
     if rank == 0:
         bps = algorithmic_bytes_per_sim(A, S_dim, dbar)
         ach = bps * G * S / (kernel_ms * 1e-3) / 1e9
-        fl = flops_per_sim(A, S_dim, H, L) * G * S / (kernel_ms * 1e-3) / 1e12
-        out["roofline"] = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": ach / HBM_PEAK_GBS, "traffic": None,
+        fps = flops_per_sim(A, S_dim, H, L)
+        fl = fps * G * S / (kernel_ms * 1e-3) / 1e12
+        # The fused kernel holds both halves of the path: the tree work (HBM-roofline accounting,
+        # SURVEY.md 8d bytes) and the MLP on v_mfma_f32_4x4x1 (MFMA-roofline accounting).  The
+        # larger fraction is reported as the bound; the other one rides along.  `traffic` = HBM
+        # bytes per launch from rocprofv3 PMC passes (FETCH_SIZE + WRITE_SIZE, KiB units of the
+        # guide), read from the committed profile of this same command.
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+                tj = json.load(f)
+            if tj.get("games") == G and tj.get("sims") == S:
+                traffic = tj["hbm_bytes_per_launch"]
+        except (OSError, ValueError, KeyError):
+            pass
+        out["roofline"] = {"bound": "mfma", "achieved": fl, "peak": F32_MATRIX_PEAK_TFLOPS,
+                           "unit": "TFLOP/s", "frac": fl / F32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
                            "kernel": "k_search_quad<31,2,64,false>", "kernel_ms": kernel_ms,
-                           "bytes_per_sim": bps, "mean_path_len": dbar,
-                           "mfma_equiv": {"achieved": fl, "peak": F32_MATRIX_PEAK_TFLOPS,
-                                          "unit": "TFLOP/s", "frac": fl / F32_MATRIX_PEAK_TFLOPS,
-                                          "flops_per_sim": flops_per_sim(A, S_dim, H, L)},
-                           "note": "latency/occupancy-bound at this model size (SURVEY.md §8d)"}
+                           "flops_per_sim": fps, "mean_path_len": dbar,
+                           "hbm_equiv": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                         "frac": ach / HBM_PEAK_GBS, "bytes_per_sim": bps},
+                           "note": "neither roofline binds at this model size: one wave per SIMD, "
+                                   "instruction issue 63 % / LDS waits 31 % of wave cycles "
+                                   "(profiles/r1c_quad_summary.md, DESIGN.md 4)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, w["blob"], S, eng.pbc)
         print(json.dumps(out), flush=True)

@@ -19,7 +19,8 @@
  *   sum      : adjacent-pair tree over the array zero-padded to a power of two
  *              (v[i] = v[2i] + v[2i+1], repeated) == lane-local pair sum followed by a
  *              wave xor-butterfly (a + b == b + a bitwise)
- *   exp      : mzs_expf below (Cody-Waite reduction + degree-6 Cephes polynomial)
+ *   exp      : mzs_expf below (argument clamped to [-87, 88], Cody-Waite reduction + degree-6
+ *              Cephes polynomial)
  *   expm1    : mzs_expm1f_neg below, x <= 0 only (ELU negative branch)
  *   sqrt, /  : correctly rounded (hipcc: -fhip-fp32-correctly-rounded-divide-sqrt)
  *
@@ -77,29 +78,28 @@ MZS_FN float mzs_exp_reduce(float x, int* n_out) {
     return r;
 }
 
-/* exp(x); results below FLT_MIN flush to 0, inputs above 88 saturate.  Branch-free on
- * purpose: on the GPU four of these run interleaved in one basic block. */
+/* exp(x) with the argument clamped to [-87, 88] (e^-87 = 1.6e-38 stands in for anything
+ * smaller).  Branch-free on purpose: on the GPU four of these run interleaved in one basic
+ * block; the clamps are one v_max / v_min each. */
 MZS_FN float mzs_expf(float x) {
-    float xc = x > 88.0f ? 88.0f : x;
-    xc = xc < -87.0f ? -87.0f : xc;
+    float xc = __builtin_fminf(x, 88.0f);
+    xc = __builtin_fmaxf(xc, -87.0f);
     int n;
     float r = mzs_exp_reduce(xc, &n);
     float e = mzs_expm1_poly(r) + 1.0f;
-    e = e * mzs_pow2i(n);
-    return x < -87.0f ? 0.0f : e;
+    return e * mzs_pow2i(n);
 }
 
-/* expm1(x) for x <= 0: 2^n * (e^r - 1) + (2^n - 1), one fma at the end (branch-free;
- * x > 0 is evaluated as x = 0). */
+/* expm1(x) for x <= 0: 2^n * (e^r - 1) + (2^n - 1), one fma at the end (branch-free; x > 0 is
+ * evaluated as x = 0, x < -87 as -87, where the result has long rounded to -1). */
 MZS_FN float mzs_expm1f_neg(float x) {
-    float xc = x > 0.0f ? 0.0f : x;
-    xc = xc < -87.0f ? -87.0f : xc;
+    float xc = __builtin_fminf(x, 0.0f);
+    xc = __builtin_fmaxf(xc, -87.0f);
     int n;
     float r = mzs_exp_reduce(xc, &n);
     float p = mzs_expm1_poly(r);
     float s = mzs_pow2i(n);
-    float y = mzs_fma(s, p, s - 1.0f);
-    return x < -87.0f ? -1.0f : y;
+    return mzs_fma(s, p, s - 1.0f);
 }
 
 /* torch.nn.ELU(alpha=1) */
