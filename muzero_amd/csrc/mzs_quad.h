@@ -82,8 +82,25 @@ __device__ __forceinline__ float high_half(float v) {
     return hi;
 }
 
-/* no NaNs on this path; v_max_f32 instead of compare + select */
-__device__ __forceinline__ float fmax_sel(float a, float b) { return __builtin_fmaxf(a, b); }
+/* No NaNs on this path: plain v_max_f32 (fmaxf() would add a canonicalising v_max per operand). */
+__device__ __forceinline__ float fmax_sel(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+/* max(v, v of the lane 8 / 4 further round the row) in one DPP instruction.  The s_nop covers the
+ * VALU-write -> DPP-read hazard, which the compiler cannot see inside an asm string. */
+__device__ __forceinline__ float max_ror8(float v) {
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
+__device__ __forceinline__ float max_ror4(float v) {
+    float r;
+    asm("s_nop 1\n\tv_max_f32_dpp %0, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf" : "=v"(r) : "v"(v));
+    return r;
+}
 
 /* reductions over the 8 blocks of this lane's half, per game (result in every lane of the half) */
 __device__ __forceinline__ float half_sum(float v) {
@@ -95,8 +112,8 @@ __device__ __forceinline__ float half_sum(float v) {
 }
 
 __device__ __forceinline__ float half_max(float v) {
-    v = fmax_sel(v, dpp_mov<kDppRowRor8>(v));
-    v = fmax_sel(v, dpp_mov<kDppRowRor4>(v));
+    v = max_ror8(v);
+    v = max_ror4(v);
     float x, y;
     rows_pair(v, x, y);
     return fmax_sel(x, y);
@@ -240,14 +257,35 @@ __device__ __forceinline__ f32x4 quad_softmax(const f32x4 o, const bool (&valid)
     return e;
 }
 
-/* expectation over the support i - SD/2 of probabilities p, then the inverse value transform
- * (muzero_model.py:580-586) */
+/* expectation over the support i - SD/2 of probabilities p (muzero_model.py:580-584); the
+ * inverse value transform is applied once for reward and value together (quad_inverse2) */
 template <int SD>
-__device__ __forceinline__ float quad_support_scalar(const f32x4 p, const bool (&valid)[4], int i0) {
+__device__ __forceinline__ float quad_support_mean(const f32x4 p, const bool (&valid)[4], int i0) {
     f32x4 t;
 #pragma unroll
     for (int r = 0; r < 4; ++r) t[r] = valid[r] ? (float)(i0 + r - SD / 2) * p[r] : 0.0f;
-    return mzs_inverse_value_transform(half_sum(sum4(t)));
+    return half_sum(sum4(t));
+}
+
+/* mzs_inverse_value_transform (muzero_model.py:585-586) with its division by the constant 0.002
+ * done as a corrected-reciprocal quotient (same correctly rounded result, see div_r2) */
+__device__ __forceinline__ float quad_inverse_value_transform(float y) {
+    const float a = __builtin_fabsf(y);
+    float t = (a + 1.0f) + 0.001f;
+    t = 0.004f * t;
+    t = 1.0f + t;
+    float r = __builtin_sqrtf(t);
+    r = r - 1.0f;
+    {
+        const float d = 0.002f, rc = 1.0f / 0.002f; /* constant-folded, correctly rounded */
+        float q = r * rc;
+        q = mzs_fma(mzs_fma(-q, d, r), rc, q);
+        r = mzs_fma(mzs_fma(-q, d, r), rc, q);
+    }
+    r = r * r;
+    r = r - 1.0f;
+    const float sg = (y > 0.0f) ? 1.0f : ((y < 0.0f) ? -1.0f : 0.0f);
+    return sg * r;
 }
 
 /* scale_to_bound_action (neural_network_mlp_model.py:135-143) of this lane's half */
@@ -266,7 +304,8 @@ __device__ __forceinline__ f32x4 quad_scale_to_bound(const f32x4 o, const bool (
 
 /* Prediction_function on the hidden-state row `h` of each game (LDS): policy logits in the
  * low half (block eb = 0 holds actions 0..3: lanes 0..3), value logits in the high half; the two
- * softmaxes run in the same instructions.  Returns the value in the high half's lanes. */
+ * softmaxes run in the same instructions.  Returns the value's support expectation (before the
+ * inverse transform) in the high half's lanes. */
 template <int SD, int NA, int H>
 __device__ __forceinline__ float quad_prediction(const QuadWeights<SD, NA, H>& W, const QuadLds& L,
                                                  const QuadLane& q, const float* h, f32x4* prior) {
@@ -280,12 +319,12 @@ __device__ __forceinline__ float quad_prediction(const QuadWeights<SD, NA, H>& W
     const f32x4 p = quad_softmax(acc, valid);
     *prior = p;
     const bool vv[4] = {valid[0] && q.half, valid[1] && q.half, valid[2] && q.half, valid[3] && q.half};
-    return quad_support_scalar<SD>(p, vv, i0);
+    return quad_support_mean<SD>(p, vv, i0);
 }
 
 /* Dynamics_function on row `h` + action: reward logits in the low half, next-state
  * pre-activations in the high half; the new hidden state goes to row `hn` (LDS).  Returns the
- * reward in the low half's lanes. */
+ * reward's support expectation (before the inverse transform) in the low half's lanes. */
 template <int SD, int NA, int H>
 __device__ __forceinline__ float quad_dynamics(const QuadWeights<SD, NA, H>& W, const QuadLds& L,
                                                const QuadLane& q, const float* h, int action, float* hn) {
@@ -301,7 +340,7 @@ __device__ __forceinline__ float quad_dynamics(const QuadWeights<SD, NA, H>& W, 
     const bool valid[4] = {i0 < SD, i0 + 1 < SD, i0 + 2 < SD, i0 + 3 < SD};
     /* reward head */
     const f32x4 p = quad_softmax(acc, valid);
-    const float reward = quad_support_scalar<SD>(p, valid, i0);
+    const float reward = quad_support_mean<SD>(p, valid, i0);
     /* next state */
     const f32x4 y = quad_scale_to_bound(acc, valid);
     if (q.half) store4(hn + i0, y);

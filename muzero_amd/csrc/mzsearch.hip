@@ -337,7 +337,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
         for (int k = q.b; k < m.obs_dim; k += 16) L.trunk[q.c * 64 + k] = p.obs[(size_t)g * m.obs_dim + k];
         wave_sync();
         quad_representation<SD, NA, H>(m, L, q, L.hid);
-        (void)quad_prediction<SD, NA, H>(W, L, q, L.hid, &pr);
+        (void)quad_prediction<SD, NA, H>(W, L, q, L.hid, &pr);   /* the root's value is not used */
     }
     if (q.b == 0) {
 #pragma unroll
@@ -379,10 +379,12 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
             /* dynamics on the parent's hidden state, prediction on the new one (mcts.py:180-192) */
             const int e_parent = (sel.pbase - 1) / NA;
             float* hn = L.hid + e_new * 32;
-            reward = low_half(quad_dynamics<SD, NA, H>(W, L, q, L.hid + e_parent * 32, sel.action, hn));
+            const float yr = quad_dynamics<SD, NA, H>(W, L, q, L.hid + e_parent * 32, sel.action, hn);
             DIAG_T(t2);
             DIAG_ADD(2, t1, t2);
-            value = high_half(quad_prediction<SD, NA, H>(W, L, q, hn, &pr));
+            const float yv = quad_prediction<SD, NA, H>(W, L, q, hn, &pr);
+            /* one inverse transform for both scalars: reward in the low half, value in the high */
+            halves_pair(quad_inverse_value_transform(q.half ? yv : yr), reward, value);
         }
         DIAG_T(t3);
         /* expand (mcts.py:186-200) */
