@@ -78,6 +78,17 @@ int mzs_search(mzs_handle* h, int32_t n_games, int32_t num_simulations, int32_t 
                const float* obs_dev, const double* dirichlet_dev, const double* noise_dev,
                int64_t noise_stride, void* stream);
 
+/* The per-game random streams mzs_search consumes, generated on the device: for game g exactly
+ * what numpy.random.RandomState(seeds[g]) returns for dirichlet([alpha] * A) (only when train and
+ * num_simulations > 0) followed by uniform(lo, hi, size = mzs_max_draws(A, S)) — i.e. what the
+ * reference draws from NumPy's global stream after np.random.seed(seed)
+ * (monte_carlo_tree_search.py:140, :163 with lo = 1e-7, hi = 2e-7).  Uniform draws are bit-exact;
+ * the Dirichlet goes through the device's fp64 log / pow (within an ulp or two of NumPy's).
+ * seeds_dev [n_games] i64 in [0, 2^32); 0 < alpha <= 1. */
+int mzs_fill_streams(mzs_handle* h, int32_t n_games, int32_t num_simulations, int32_t train,
+                     const int64_t* seeds_dev, double alpha, double lo, double hi,
+                     double* dirichlet_dev, double* noise_dev, int64_t noise_stride, void* stream);
+
 /* Same search with the model outputs supplied instead of computed (L1 parity mode): isolates
  * ucb_score/select_child/expand/backup (mcts.py:155-209) from the network arithmetic.
  *   root_policy_dev [n_games][A], sim_reward_dev/sim_value_dev [n_games][S],

@@ -42,6 +42,8 @@ _SIGNATURES = {
     "mzs_set_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mzs_search": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_int64, C.c_void_p]),
+    "mzs_fill_streams": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_double,
+                                   C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mzs_search_injected": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_void_p]),

@@ -491,6 +491,139 @@ __global__ void __launch_bounds__(256) k_inference(const InferParams p) {
     }
 }
 
+/* ------------------------------------------------------------------------------
+ * Per-game random streams on the device: what numpy.random.RandomState(seed) yields for
+ * dirichlet([alpha] * A) followed by uniform(lo, hi, size = n) — the numbers the reference
+ * draws from NumPy's global legacy stream after np.random.seed(seed)
+ * (monte_carlo_tree_search.py:140, :163).  MT19937 (init_genrand seeding, 53-bit doubles from
+ * two tempered words), legacy standard_gamma for shape <= 1.  One wavefront per game, generator
+ * state in LDS; every lane runs the scalar parts redundantly, the state refresh and the uniform
+ * fill are spread over the lanes.
+ * ---------------------------------------------------------------------------- */
+struct FillParams {
+    const long long* seeds;
+    int n_games, A, n_uniform, train;
+    long long stride;
+    double alpha, lo, range;
+    double* dirichlet;
+    double* noise;
+};
+
+constexpr int kMtN = 624, kMtM = 397;
+
+__device__ __forceinline__ unsigned mt_temper(unsigned y) {
+    y ^= y >> 11;
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= y >> 18;
+    return y;
+}
+
+/* regenerate all 624 words (mt19937_gen of NumPy's legacy generator), 64 at a time */
+__device__ __forceinline__ void mt_twist(unsigned* mt, int lane) {
+    for (int base = 0; base < kMtN; base += kWave) {
+        const int kk = base + lane;
+        unsigned v = 0;
+        if (kk < kMtN) {
+            const unsigned y = (mt[kk] & 0x80000000u) | (mt[kk + 1 == kMtN ? 0 : kk + 1] & 0x7fffffffu);
+            const unsigned src = kk < kMtN - kMtM ? mt[kk + kMtM] : mt[kk - (kMtN - kMtM)];
+            v = src ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        wave_sync();
+        if (kk < kMtN) mt[kk] = v;
+        wave_sync();
+    }
+}
+
+struct MtStream {
+    unsigned* mt;
+    int pos, lane;
+    __device__ __forceinline__ unsigned word() {
+        if (pos == kMtN) {
+            mt_twist(mt, lane);
+            pos = 0;
+        }
+        return mt_temper(mt[pos++]);
+    }
+    /* random_double of the legacy generator */
+    __device__ __forceinline__ double next_double() {
+        const unsigned a = word() >> 5, b = word() >> 6;
+        return ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+    }
+};
+
+/* legacy_standard_gamma, shape <= 1 (numpy/random/src/legacy/legacy-distributions.c) */
+__device__ __forceinline__ double mt_standard_gamma(MtStream& r, double shape) {
+    if (shape == 1.0) return -log(1.0 - r.next_double());
+    if (shape == 0.0) return 0.0;
+    for (;;) {
+        const double U = r.next_double();
+        const double V = -log(1.0 - r.next_double());
+        if (U <= 1.0 - shape) {
+            const double X = pow(U, 1.0 / shape);
+            if (X <= V) return X;
+        } else {
+            const double Y = -log((1.0 - U) / shape);
+            const double X = pow(1.0 - shape + shape * Y, 1.0 / shape);
+            if (X <= V + Y) return X;
+        }
+    }
+}
+
+__global__ void __launch_bounds__(256) k_fill_streams(const FillParams p) {
+    __shared__ unsigned mt_s[4][kMtN];
+    __shared__ double gam_s[4][64];
+    const int lane = lane_id(), wave = threadIdx.x >> 6;
+    const int g = blockIdx.x * 4 + wave;
+    if (g >= p.n_games) return; /* no block-level barrier below */
+    MtStream r;
+    r.mt = mt_s[wave];
+    r.lane = lane;
+    r.pos = kMtN;
+    if (lane == 0) {
+        unsigned s = (unsigned)p.seeds[g]; /* mt19937_seed: init_genrand */
+        for (int i = 0; i < kMtN; ++i) {
+            r.mt[i] = s;
+            s = 1812433253u * (s ^ (s >> 30)) + (unsigned)i + 1u;
+        }
+    }
+    wave_sync();
+    if (p.train) {
+        /* RandomState.dirichlet: gamma draws, then normalise by the reciprocal of their sum */
+        double* val = gam_s[wave];
+        double acc = 0.0;
+        for (int a = 0; a < p.A; ++a) {
+            const double v = mt_standard_gamma(r, p.alpha);
+            if (lane == 0) val[a] = v;
+            acc += v;
+        }
+        wave_sync();
+        const double inv = 1.0 / acc;
+        for (int a = lane; a < p.A; a += kWave) p.dirichlet[(size_t)g * p.A + a] = val[a] * inv;
+    }
+    /* uniform(lo, hi): lo + (hi - lo) * random_double, two words per draw, lanes in parallel */
+    double* out = p.noise + (size_t)g * p.stride;
+    int done = 0;
+    while (done < p.n_uniform) {
+        if (r.pos == kMtN) {
+            mt_twist(r.mt, lane);
+            r.pos = 0;
+        }
+        const int avail = (kMtN - r.pos) / 2;
+        const int n = min(avail, p.n_uniform - done);
+        for (int i = lane; i < n; i += kWave) {
+            const unsigned a = mt_temper(r.mt[r.pos + 2 * i]) >> 5;
+            const unsigned b = mt_temper(r.mt[r.pos + 2 * i + 1]) >> 6;
+            const double d = ((double)a * 67108864.0 + (double)b) / 9007199254740992.0;
+            const double sc = p.range * d;
+            out[done + i] = p.lo + sc;
+        }
+        r.pos += 2 * n;
+        done += n;
+        wave_sync();
+    }
+}
+
 }  // namespace
 
 /* ================================================================== host side */
@@ -1201,5 +1334,39 @@ int mzs_get_weights(mzs_handle* h, float* blob_out, size_t n_floats) {
     return MZS_OK;
 }
 
-}  // extern "C"
+int mzs_fill_streams(mzs_handle* h, int32_t n_games, int32_t num_simulations, int32_t train,
+                     const int64_t* seeds_dev, double alpha, double lo, double hi,
+                     double* dirichlet_dev, double* noise_dev, int64_t noise_stride, void* stream) {
+    if (!h) return fail(MZS_E_ARG, "null handle");
+    if (n_games < 0 || num_simulations < 0) return fail(MZS_E_ARG, "bad sizes");
+    const int A = h->cfg.dims.n_actions;
+    const int64_t n_u = mzs_max_draws(A, num_simulations);
+    if (!seeds_dev || (n_u > 0 && (!noise_dev || noise_stride < n_u)))
+        return fail(MZS_E_ARG, "seeds / noise buffer missing or noise_stride < mzs_max_draws(A, S)");
+    const int do_dir = train && num_simulations > 0;
+    if (do_dir && !dirichlet_dev) return fail(MZS_E_ARG, "train=1 needs dirichlet_dev");
+    if (do_dir && !(alpha > 0.0 && alpha <= 1.0))
+        return fail(MZS_E_ARG, "device Dirichlet implements NumPy's legacy gamma sampler for 0 < alpha <= 1 "
+                               "only (draw the streams on the host for larger alpha)");
+    if (n_u >= (1ll << 31)) return fail(MZS_E_ARG, "stream too long");
+    if (n_games == 0) return MZS_OK;
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    FillParams p;
+    p.seeds = reinterpret_cast<const long long*>(seeds_dev);
+    p.n_games = n_games;
+    p.A = A;
+    p.n_uniform = (int)n_u;
+    p.train = do_dir;
+    p.stride = noise_stride;
+    p.alpha = alpha;
+    p.lo = lo;
+    p.range = hi - lo;
+    p.dirichlet = dirichlet_dev;
+    p.noise = noise_dev;
+    hipLaunchKernelGGL(k_fill_streams, dim3((n_games + 3) / 4), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), p);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
 
+}  // extern "C"

@@ -112,6 +112,23 @@ class SearchEngine:
                                        self._stream()), "mzs_search")
         self.n_games, self.num_simulations = G, int(num_simulations)
 
+    def fill_streams(self, seeds, num_simulations, train=True, lo=1e-7, hi=2e-7):
+        """Per-game streams generated on the device (mzs_fill_streams): returns device tensors
+        (dirichlet [G, A] f64 or None, noise [G, max_draws] f64) equal to
+        rng.noise_streams(seeds, ...) — uniforms bit for bit, Dirichlet to an ulp or two."""
+        seeds = self._dev(np.asarray(seeds, dtype=np.int64) if not isinstance(seeds, torch.Tensor) else seeds,
+                          torch.int64)
+        G, S = seeds.shape[0], int(num_simulations)
+        stride = max(1, rng.max_draws(self.A, S))
+        do_dir = bool(train) and S > 0
+        dirichlet = torch.empty((G, self.A), dtype=torch.float64, device=self.device) if do_dir else None
+        noise = torch.empty((G, stride), dtype=torch.float64, device=self.device)
+        _lib.check(self.lib.mzs_fill_streams(self.h, G, S, int(bool(train)), _ptr(seeds), self.alpha,
+                                             float(lo), float(hi), _ptr(dirichlet), _ptr(noise), stride,
+                                             self._stream()), "mzs_fill_streams")
+        self._keep_seeds = seeds
+        return dirichlet, noise
+
     def search_injected(self, table, dirichlet, noise, num_simulations, train=True):
         """L1 mode: `table` = dict(root_policy [G,A], sim_reward [G,S], sim_value [G,S],
         sim_prior [G,S,A]) holds the model outputs to use instead of computing them."""
@@ -207,7 +224,9 @@ class SearchEngine:
         Dirichlet, then the tie-break uniforms — what the reference's global stream yields
         after np.random.seed(seed)), search, and return host arrays."""
         S = self.max_simulations if num_simulations is None else int(num_simulations)
-        if noise is None:
+        if noise is None and 0.0 < self.alpha <= 1.0:
+            dirichlet, noise = self.fill_streams(seeds, S, train)          # on the device
+        elif noise is None:
             dirichlet, noise = rng.noise_streams(seeds, self.A, S, self.alpha, train)
         self.search(observations, dirichlet if (train and S > 0) else None,
                     noise if S > 0 else None, S, train)
