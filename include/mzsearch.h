@@ -180,6 +180,76 @@ int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, dou
 /* current weights in blob order, to a host or device buffer (synchronises the device) */
 int mzs_get_weights(mzs_handle* h, float* blob_out, size_t n_floats);
 
+/* ---- self-play arena: what sits on either side of the search ---------
+ * n_slots concurrent episodes of a built-in environment, their trajectories in HBM (n_rows
+ * trajectory rows of max_moves moves: the Game objects' lists, game.py:46-55), and the gather of
+ * training batches from them. */
+#define MZS_ENV_CARTPOLE 0 /* Gymnasium CartPole-v1 restated from its equations (include/mzs_env.h) */
+
+typedef struct mzs_arena mzs_arena;
+typedef struct mzs_arena_config {
+    int32_t device;
+    int32_t env;        /* MZS_ENV_*                                                   */
+    int32_t n_slots;    /* G: episodes played at once (= games per search batch)       */
+    int32_t n_rows;     /* trajectory rows kept in HBM (the replay window), >= n_slots  */
+    int32_t max_moves;  /* limit_of_game_play (gameplay section of the config)         */
+} mzs_arena_config;
+
+int mzs_arena_create(const mzs_arena_config* cfg, mzs_arena** out);
+void mzs_arena_destroy(mzs_arena* arena);
+int32_t mzs_arena_obs_dim(const mzs_arena* arena);
+int32_t mzs_arena_n_actions(const mzs_arena* arena);
+
+/* Start of a round of n_games episodes (learning_cycle's number_of_self_play_before_training
+ * play_game calls, self_play.py:230-236) recorded in trajectory rows [row0, row0 + n_games):
+ * Game() + Game.observation(iteration=0) (game.py:126-141).  Game i is reset from the counter-based
+ * generator keyed by (seeds_dev[i], episode).  The first min(n_slots, n_games) games start now, in
+ * slots 0, 1, ...; every later game starts in the slot freed by a finished one, so the n_slots
+ * searches of a move stay full until the round runs out of games.  obs_dev [n_slots][obs_dim]
+ * receives the first observations. */
+int mzs_arena_begin(mzs_arena* arena, int32_t row0, int32_t n_games, const int64_t* seeds_dev, int32_t episode,
+                    float* obs_dev, void* stream);
+
+/* One move of every live slot, fed with this move's search results (mzs_results layout):
+ * Game.store_search_statistics (game.py:154-168), Game.policy_step (game.py:176-225: temperature
+ * rescale, np.random.choice above temperature 0.1 else argmax, env.step, append to the lists);
+ * then free slots take the round's next unplayed games in slot order.  obs_dev is overwritten
+ * with the next observations (the reset observation for a newly started game);
+ * *alive_count_dev = slots with a running game afterwards (0: the round is complete — play_game's
+ * loop condition, self_play.py:62, has ended every game).  MZS_ARENA_STREAM_SEED holds, per slot,
+ * the seed of the RandomState stream its next search draws from (mzs_fill_streams). */
+int mzs_arena_step(mzs_arena* arena, const int32_t* visits_dev, const float* root_value_dev,
+                   const double* root_prior_dev, double temperature, float* obs_dev,
+                   int32_t* alive_count_dev, void* stream);
+
+/* ReplayBuffer.sample_batch's per-sample work (replay_buffer.py:147-151: make_image,
+ * fill_gap_empty_action, Game.make_target game.py:237-260) for `batch` (row, position) pairs
+ * chosen by the caller, written in the layout mzs_train_grad reads.  discount_pow_dev [td+1] =
+ * discount ** i evaluated on the host as Python does. */
+int mzs_arena_make_batch(mzs_arena* arena, int32_t batch, const int32_t* row_pos_dev, int32_t unroll_steps,
+                         int32_t td_steps, const double* discount_pow_dev, float* obs_dev, float* actions_dev,
+                         float* target_value_dev, float* target_reward_dev, float* target_policy_dev,
+                         void* stream);
+
+/* Game.make_priority (game.py:262-284) for trajectory rows [row0, row0 + n_rows): priority_dev
+ * [n_rows][out_stride] f64 = |root_value - n-step value target| per position (0 from the end of
+ * the game on; out_stride may be smaller than max_moves when the caller knows the longest game).
+ * ReplayBuffer.save_game (replay_buffer.py:70-79) takes the per-game maximum of it. */
+int mzs_arena_priority(mzs_arena* arena, int32_t row0, int32_t n_rows, int32_t td_steps,
+                       const double* discount_pow_dev, int32_t out_stride, double* priority_dev, void* stream);
+
+#define MZS_ARENA_LENGTH 0     /* i32 [n_rows]                  game_length            */
+#define MZS_ARENA_OBS 1        /* f32 [n_rows][T][obs_dim]      observations            */
+#define MZS_ARENA_ACTION 2     /* i32 [n_rows][T]               action_history (index)  */
+#define MZS_ARENA_REWARD 3     /* f32 [n_rows][T]               rewards                 */
+#define MZS_ARENA_ROOT_VALUE 4 /* f32 [n_rows][T]               root_values             */
+#define MZS_ARENA_POLICY 5     /* f32 [n_rows][T][A]            child_visits            */
+#define MZS_ARENA_ALIVE 6      /* i32 [n_slots]                                         */
+#define MZS_ARENA_STATE 7      /* f64 [n_slots][4]              environment state       */
+#define MZS_ARENA_STREAM_SEED 8 /* i64 [n_slots]                seed of the next search streams */
+#define MZS_ARENA_SLOT_ROW 9   /* i32 [n_slots]                 row the slot records into */
+void* mzs_arena_array(mzs_arena* arena, int32_t which);
+
 const char* mzs_last_error(void);
 const char* mzs_version(void);
 

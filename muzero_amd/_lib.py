@@ -29,6 +29,16 @@ class Dims(C.Structure):
                 ("hidden_dim", C.c_int32), ("n_mid_layers", C.c_int32)]
 
 
+class ArenaConfig(C.Structure):
+    _fields_ = [("device", C.c_int32), ("env", C.c_int32), ("n_slots", C.c_int32), ("n_rows", C.c_int32),
+                ("max_moves", C.c_int32)]
+
+
+ARENA_LENGTH, ARENA_OBS, ARENA_ACTION, ARENA_REWARD, ARENA_ROOT_VALUE, ARENA_POLICY = 0, 1, 2, 3, 4, 5
+ARENA_ALIVE, ARENA_STATE, ARENA_STREAM_SEED, ARENA_SLOT_ROW = 6, 7, 8, 9
+ENV_CARTPOLE = 0
+
+
 class Config(C.Structure):
     _fields_ = [("dims", Dims), ("max_games", C.c_int32), ("max_simulations", C.c_int32),
                 ("device", C.c_int32), ("engine", C.c_int32), ("discount", C.c_double),
@@ -65,6 +75,19 @@ _SIGNATURES = {
                                  C.c_void_p]),
     "mzs_train_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
     "mzs_get_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "mzs_arena_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "mzs_arena_destroy": (None, [C.c_void_p]),
+    "mzs_arena_obs_dim": (C.c_int32, [C.c_void_p]),
+    "mzs_arena_n_actions": (C.c_int32, [C.c_void_p]),
+    "mzs_arena_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
+                                  C.c_void_p]),
+    "mzs_arena_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+    "mzs_arena_make_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mzs_arena_priority": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                     C.c_void_p, C.c_void_p]),
+    "mzs_arena_array": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "mzs_last_error": (C.c_char_p, []),
     "mzs_version": (C.c_char_p, []),
 }

@@ -19,6 +19,7 @@
 #include "mzs_device.h"
 #include "mzs_quad.h"
 #include "mzs_train.h"
+#include "mzs_selfplay.h"
 
 using namespace mzs;
 
@@ -1367,6 +1368,152 @@ int mzs_fill_streams(mzs_handle* h, int32_t n_games, int32_t num_simulations, in
                        static_cast<hipStream_t>(stream), p);
     HIP_TRY(hipGetLastError());
     return MZS_OK;
+}
+
+}  // extern "C" (reopened below)
+
+/* ------------------------------------------------------------------ self-play arena */
+
+struct mzs_arena {
+    mzs_arena_config cfg;
+    ArenaArrays a;
+    int* alive_count_dev = nullptr;
+    std::vector<void*> allocs;
+};
+
+namespace {
+template <typename T>
+int arena_alloc(mzs_arena* ar, T** out, size_t n) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, n * sizeof(T) + 256));
+    HIP_TRY(hipMemset(p, 0, n * sizeof(T) + 256));
+    ar->allocs.push_back(p);
+    *out = static_cast<T*>(p);
+    return MZS_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int mzs_arena_create(const mzs_arena_config* cfg, mzs_arena** out) {
+    if (!cfg || !out) return fail(MZS_E_ARG, "null argument");
+    if (cfg->env != MZS_ENV_CARTPOLE) return fail(MZS_E_ARG, "unknown environment (only MZS_ENV_CARTPOLE)");
+    if (cfg->n_slots < 1 || cfg->n_rows < cfg->n_slots || cfg->max_moves < 1)
+        return fail(MZS_E_ARG, "need n_slots >= 1, n_rows >= n_slots, max_moves >= 1");
+    HIP_TRY(hipSetDevice(cfg->device));
+    mzs_arena* ar = new (std::nothrow) mzs_arena();
+    if (!ar) return fail(MZS_E_ARG, "out of host memory");
+    ar->cfg = *cfg;
+    ArenaArrays& a = ar->a;
+    a.G = cfg->n_slots, a.n_rows = cfg->n_rows, a.T = cfg->max_moves, a.obs_dim = 4, a.A = 2;
+    const size_t G = a.G, R = a.n_rows, T = a.T;
+    int rc;
+    if ((rc = arena_alloc(ar, &a.state, G * 4)) || (rc = arena_alloc(ar, &a.alive, G)) ||
+        (rc = arena_alloc(ar, &a.row, G)) || (rc = arena_alloc(ar, &a.seed, G)) ||
+        (rc = arena_alloc(ar, &a.episode, G)) || (rc = arena_alloc(ar, &a.stream_seed, G)) ||
+        (rc = arena_alloc(ar, &a.ctl, 2)) || (rc = arena_alloc(ar, &a.row_seed, R)) ||
+        (rc = arena_alloc(ar, &a.length, R)) ||
+        (rc = arena_alloc(ar, &a.obs, R * T * a.obs_dim)) || (rc = arena_alloc(ar, &a.action, R * T)) ||
+        (rc = arena_alloc(ar, &a.reward, R * T)) || (rc = arena_alloc(ar, &a.root_value, R * T)) ||
+        (rc = arena_alloc(ar, &a.policy, R * T * a.A)) || (rc = arena_alloc(ar, &ar->alive_count_dev, 1))) {
+        mzs_arena_destroy(ar);
+        return rc;
+    }
+    *out = ar;
+    return MZS_OK;
+}
+
+void mzs_arena_destroy(mzs_arena* ar) {
+    if (!ar) return;
+    (void)hipSetDevice(ar->cfg.device);
+    for (void* p : ar->allocs) (void)hipFree(p);
+    delete ar;
+}
+
+int32_t mzs_arena_obs_dim(const mzs_arena* ar) { return ar ? ar->a.obs_dim : 0; }
+int32_t mzs_arena_n_actions(const mzs_arena* ar) { return ar ? ar->a.A : 0; }
+
+int mzs_arena_begin(mzs_arena* ar, int32_t row0, int32_t n_games, const int64_t* seeds_dev, int32_t episode,
+                    float* obs_dev, void* stream) {
+    if (!ar || !seeds_dev || !obs_dev) return fail(MZS_E_ARG, "null argument");
+    if (n_games < 1 || row0 < 0 || row0 + n_games > ar->a.n_rows)
+        return fail(MZS_E_ARG, "rows [row0, row0 + n_games) out of range");
+    HIP_TRY(hipSetDevice(ar->cfg.device));
+    const int n = n_games > ar->a.G ? n_games : ar->a.G;
+    hipLaunchKernelGGL(k_arena_begin, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       ar->a, row0, n_games, reinterpret_cast<const long long*>(seeds_dev), episode, obs_dev);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
+int mzs_arena_step(mzs_arena* ar, const int32_t* visits_dev, const float* root_value_dev,
+                   const double* root_prior_dev, double temperature, float* obs_dev, int32_t* alive_count_dev,
+                   void* stream) {
+    if (!ar || !visits_dev || !root_value_dev || !root_prior_dev || !obs_dev || !alive_count_dev)
+        return fail(MZS_E_ARG, "null argument");
+    HIP_TRY(hipSetDevice(ar->cfg.device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_arena_step, dim3((ar->a.G + 255) / 256), dim3(256), 0, st, ar->a, visits_dev,
+                       root_value_dev, root_prior_dev, temperature, obs_dev);
+    hipLaunchKernelGGL(k_arena_refill, dim3(1), dim3(kRefillThreads), 0, st, ar->a, obs_dev, alive_count_dev);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
+int mzs_arena_make_batch(mzs_arena* ar, int32_t batch, const int32_t* row_pos_dev, int32_t unroll_steps,
+                         int32_t td_steps, const double* discount_pow_dev, float* obs_dev, float* actions_dev,
+                         float* target_value_dev, float* target_reward_dev, float* target_policy_dev,
+                         void* stream) {
+    if (!ar || !row_pos_dev || !discount_pow_dev || !obs_dev || !actions_dev || !target_value_dev ||
+        !target_reward_dev || !target_policy_dev)
+        return fail(MZS_E_ARG, "null argument");
+    if (batch < 0 || unroll_steps < 1 || td_steps < 0) return fail(MZS_E_ARG, "bad sizes");
+    if (batch == 0) return MZS_OK;
+    HIP_TRY(hipSetDevice(ar->cfg.device));
+    BatchParams p;
+    p.a = ar->a;
+    p.B = batch, p.K = unroll_steps, p.td = td_steps;
+    p.row_pos = row_pos_dev;
+    p.disc_pow = discount_pow_dev;
+    p.obs = obs_dev, p.actions = actions_dev, p.tv = target_value_dev, p.tr = target_reward_dev;
+    p.tp = target_policy_dev;
+    const int n = batch * unroll_steps;
+    hipLaunchKernelGGL(k_arena_make_batch, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
+int mzs_arena_priority(mzs_arena* ar, int32_t row0, int32_t n_rows, int32_t td_steps,
+                       const double* discount_pow_dev, int32_t out_stride, double* priority_dev, void* stream) {
+    if (!ar || !discount_pow_dev || !priority_dev) return fail(MZS_E_ARG, "null argument");
+    if (row0 < 0 || n_rows < 0 || row0 + n_rows > ar->a.n_rows || td_steps < 0 || out_stride < 1)
+        return fail(MZS_E_ARG, "rows [row0, row0 + n_rows) out of range or bad sizes");
+    if (n_rows == 0) return MZS_OK;
+    HIP_TRY(hipSetDevice(ar->cfg.device));
+    const long long total = (long long)n_rows * out_stride;
+    if (total > 0x7fffffffLL) return fail(MZS_E_ARG, "n_rows * out_stride too large");
+    hipLaunchKernelGGL(k_arena_priority, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), ar->a, row0, n_rows, td_steps, discount_pow_dev,
+                       out_stride, priority_dev);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
+void* mzs_arena_array(mzs_arena* ar, int32_t which) {
+    if (!ar) return nullptr;
+    switch (which) {
+        case MZS_ARENA_LENGTH: return ar->a.length;
+        case MZS_ARENA_OBS: return ar->a.obs;
+        case MZS_ARENA_ACTION: return ar->a.action;
+        case MZS_ARENA_REWARD: return ar->a.reward;
+        case MZS_ARENA_ROOT_VALUE: return ar->a.root_value;
+        case MZS_ARENA_POLICY: return ar->a.policy;
+        case MZS_ARENA_ALIVE: return ar->a.alive;
+        case MZS_ARENA_STATE: return ar->a.state;
+        case MZS_ARENA_STREAM_SEED: return ar->a.stream_seed;
+        case MZS_ARENA_SLOT_ROW: return ar->a.row;
+        default: return nullptr;
+    }
 }
 
 }  // extern "C"

@@ -1,0 +1,434 @@
+"""Batched self-play on the MI355X: the callers on either side of the search
+(/root/reference self_play.py, game.py, replay_buffer.py).
+
+The reference plays ONE game at a time through Python objects (Game lists, one MCTS per move,
+ReplayBuffer of Game objects).  Here G episodes advance in lock step on one GPU:
+
+  per move   fill_streams -> mzs_search (G trees) -> mzs_arena_step (store_search_statistics,
+             policy_step, env.step and the trajectory append, all in HBM)       self_play.py:62-73
+  per round  finished trajectories stay in HBM rows; the host keeps only what the reference's
+             ReplayBuffer needs to SAMPLE: lengths and priorities (ReplayStore)  replay_buffer.py
+  per batch  the host draws (game, position) pairs exactly as ReplayBuffer.sample_batch does,
+             mzs_arena_make_batch gathers observations / actions / make_target straight into the
+             buffers of the training kernels                                     replay_buffer.py:131-166
+
+Nothing here computes on the CPU what the reference computes per move; the host work is
+O(batch) index arithmetic on NumPy's own generator (so seeding np.random reproduces the
+reference's draws).
+"""
+import ctypes as C
+import math
+
+import numpy as np
+import torch
+
+from . import _lib
+from .engine import _DevView, _ptr
+
+
+# ---------------------------------------------------------------------------- schedules
+def _scaler(x, newmin=0.0, newmax=1.0):
+    """self_play.py:81-97."""
+    x = np.asarray(x, np.float64)
+    oldmin, oldmax = x.min(), x.max()
+    if oldmax == oldmin:
+        return np.full(x.shape, newmin if oldmin < newmin else (newmax if oldmin > newmax else oldmin))
+    return (x - oldmin) * ((newmax - newmin) / (oldmax - oldmin)) + newmin
+
+
+def temperature_scheduler(epoch=1, actual_epoch=1, mode="static_temperature"):
+    """self_play.py:102-139: the action-selection temperature of iteration `actual_epoch`."""
+    if mode == "reversal_tanh_temperature":
+        arr = np.arange(1, epoch + 1)
+        return float(((1 - np.tanh(_scaler(arr, 0.001, 0.75))) * 1.1)[actual_epoch - 1])
+    if mode == "extreme_temperature":
+        for frac, t in ((100, 3), (200, 2), (300, 1), (400, .7), (500, .5), (600, .4), (700, .0625)):
+            if actual_epoch < epoch * (frac / 700):
+                return t
+        return None
+    if mode == "linear_decrease_temperature":
+        return 1 if epoch * 0.5 > actual_epoch else (0.5 if epoch * 0.75 > actual_epoch else 0.2)
+    if mode == "static_temperature":
+        return 0.0
+    if mode == "static_one_temperature":
+        return 1
+    raise ValueError(f"temperature mode {mode!r}")
+
+
+# ---------------------------------------------------------------------------- priorities
+def discount_powers(discount, n):
+    """[discount ** i for i in 0..n] evaluated as the reference does (Python float pow)."""
+    return np.array([float(discount) ** i for i in range(n + 1)], np.float64)
+
+
+def make_priority(root_values, rewards, lengths, td_steps, discount):
+    """Game.make_priority (game.py:262-284) for many games at once.
+
+    root_values / rewards: [R, T] float32 rows of the arena, lengths [R].  Returns the
+    [R, T] float64 |root_value - n-step target| (entries past a game's length are 0) with the
+    reference's arithmetic under NumPy 2: the target accumulates in float32 when a bootstrap
+    value exists and in float64 otherwise (see mzs_selfplay.h target_value)."""
+    rv = np.ascontiguousarray(root_values, np.float32)
+    rw = np.ascontiguousarray(rewards, np.float32)
+    ln = np.asarray(lengths, np.int64)
+    R, T = rv.shape
+    td = int(td_steps)
+    dp = discount_powers(discount, td)
+    pos = np.arange(T)
+    has = (pos[None, :] + td) < ln[:, None]
+    boot = rv[:, np.minimum(pos + td, T - 1)] * np.float32(dp[td])
+    v32 = np.where(has, boot, np.float32(0)).astype(np.float32)
+    v64 = np.zeros((R, T), np.float64)
+    for i in range(td):
+        idx = pos + i
+        ok = idx[None, :] < ln[:, None]
+        term = rw[:, np.minimum(idx, T - 1)].astype(np.float64) * dp[i]
+        v32 = np.where(ok, v32 + term.astype(np.float32), v32)
+        v64 = np.where(ok, v64 + term, v64)
+    target = np.where(has, v32.astype(np.float64), v64)
+    prio = np.abs(rv.astype(np.float64) - target)
+    prio[pos[None, :] >= ln[:, None]] = 0.0
+    return prio
+
+
+class ReplayStore:
+    """ReplayBuffer (replay_buffer.py) over arena rows: same window rule, same priorities, same
+    draws from NumPy's generator, but a "game" is a trajectory row in HBM and a batch is a
+    [B, 2] table of (row, position) handed to mzs_arena_make_batch.
+
+    Differences that are deliberate and stated:
+      * game_sampling="uniform" raises TypeError in the reference (replay_buffer.py:96 indexes the
+        buffer with a Game object); here it draws a uniform buffer index.
+      * the per-sample np.random.choice calls are issued as one random_sample(B) per stage, which
+        consumes the generator identically (pinned by tests/test_selfplay_oracle.py)."""
+
+    def __init__(self, window_size, batch_size, num_unroll, td_steps, game_sampling="priority",
+                 position_sampling="priority", discount=0.997, rng=None):
+        for m in (game_sampling, position_sampling):
+            if m not in ("uniform", "priority"):
+                raise ValueError(f"sampling mode {m!r}")
+        self.window_size, self.batch_size = int(window_size), int(batch_size)
+        self.num_unroll, self.td_steps = int(num_unroll), int(td_steps)
+        self.game_sampling, self.position_sampling = game_sampling, position_sampling
+        self.discount = float(discount)
+        self.rng = np.random if rng is None else rng
+        self.rows = np.zeros(0, np.int64)      # buffer order -> arena row
+        self.lengths = np.zeros(0, np.int64)   # buffer order -> game_length
+        self.prio_game = np.zeros(0, np.float64)
+        self.soft_prio_game = np.zeros(0)
+        self.big_n_of_importance_sampling_ratio = 0
+        # prio_position: one [n, width] float64 block per save_games call + (block, index, length) per entry
+        self._blocks, self._next_block = {}, 0
+        self._blk, self._bidx, self._plen = (np.zeros(0, np.int64) for _ in range(3))
+
+    def __len__(self):
+        return len(self.rows)
+
+    @property
+    def uses_priority(self):
+        return "priority" in (self.game_sampling, self.position_sampling)
+
+    class _PositionPriorities:
+        """prio_position of the reference: entry g is the writable float64 [length] view."""
+
+        def __init__(self, store):
+            self.s = store
+
+        def __len__(self):
+            return len(self.s._blk)
+
+        def __getitem__(self, g):
+            s = self.s
+            return s._blocks[int(s._blk[g])][int(s._bidx[g]), : int(s._plen[g])]
+
+        def __iter__(self):
+            return (self[g] for g in range(len(self)))
+
+    @property
+    def prio_position(self):
+        return self._PositionPriorities(self)
+
+    def save_games(self, rows, lengths, root_values=None, rewards=None, priorities=None):
+        """save_game (replay_buffer.py:59-84) for a block of finished games, in order, without a
+        per-game Python loop.  priorities: [n, >= longest game] float64 from Arena.priority
+        (mzs_arena_priority), zero past each game's end; without it they are computed here from
+        [n, T] float32 host copies of root_values / rewards."""
+        rows = np.asarray(rows, np.int64).reshape(-1)
+        lengths = np.asarray(lengths, np.int64).reshape(-1)
+        m, n0 = len(rows), len(self.rows)
+        # one pop per save once the buffer holds window_size + 1 games (replay_buffer.py:61-63)
+        pops = n0 + m - min(n0 + m, self.window_size + 1)
+        if self.uses_priority:
+            if np.any(lengths == 0):
+                raise ValueError("zero-size array to reduction operation maximum which has no identity")
+            prio = priorities if priorities is not None else make_priority(root_values, rewards, lengths,
+                                                                          self.td_steps, self.discount)
+            prio = np.ascontiguousarray(prio, np.float64)
+            # as the reference: each list is popped only under its own mode although both are
+            # appended whenever either mode is "priority" (replay_buffer.py:64-67, :70-79)
+            pg = pops if self.game_sampling == "priority" else 0
+            pp = pops if self.position_sampling == "priority" else 0
+            self.prio_game = np.concatenate([self.prio_game, prio.max(axis=1)])[pg:]
+            bid, self._next_block = self._next_block, self._next_block + 1
+            self._blocks[bid] = prio
+            self._blk = np.concatenate([self._blk, np.full(m, bid, np.int64)])[pp:]
+            self._bidx = np.concatenate([self._bidx, np.arange(m, dtype=np.int64)])[pp:]
+            self._plen = np.concatenate([self._plen, lengths])[pp:]
+            for old in [k for k in self._blocks if len(self._blk) and k < int(self._blk[0])]:
+                del self._blocks[old]
+            self.soft_prio_game = self.prio_game / np.sum(self.prio_game)
+        self.rows = np.concatenate([self.rows, rows])[pops:]
+        self.lengths = np.concatenate([self.lengths, lengths])[pops:]
+        self.big_n_of_importance_sampling_ratio = int(self.lengths.sum())
+
+    @staticmethod
+    def _choice(p, u):
+        """RandomState.choice(len(p), p=p) for the uniform numbers u it would draw."""
+        if not np.all(np.isfinite(p)):
+            raise ValueError("probabilities contain NaN")
+        if np.any(p < 0):
+            raise ValueError("probabilities are not non-negative")
+        if abs(float(p.sum()) - 1.0) > 1.5e-8:
+            raise ValueError("probabilities do not sum to 1")
+        cdf = np.cumsum(p)
+        cdf /= cdf[-1]
+        return cdf.searchsorted(u, side="right")
+
+    def sample_batch(self):
+        """sample_batch (replay_buffer.py:131-166) without the gather: returns
+        (row_pos int32 [B, 2] = (arena row, position), importance_sampling_ratio, game_pos [B, 2] =
+        (buffer index, position) as the reference returns it)."""
+        B = self.batch_size
+        if self.game_sampling == "priority":
+            gi = self._choice(self.soft_prio_game, self.rng.random_sample(B))
+        else:
+            gi = self.rng.randint(0, len(self.rows), size=B)
+        pos = np.zeros(B, np.int64)
+        mouve = np.zeros(B, np.float64)
+        if np.any(self.lengths[gi] == 0):
+            raise Exception("Game need to return at least one reward")
+        prio_pos = self.position_sampling == "priority"
+        u = self.rng.random_sample(B) if prio_pos else None
+        pp, cache = self.prio_position, {}
+        for b in range(B):
+            g = int(gi[b])
+            if self.uses_priority:
+                if g not in cache:      # soft_prio_position (replay_buffer.py:102) and its cdf, once per game
+                    p = pp[g]
+                    soft = p / p.sum()
+                    cdf = None
+                    if prio_pos:
+                        if not np.isfinite(soft[-1]) or soft.min() < 0:     # what RandomState.choice rejects
+                            raise ValueError("probabilities contain NaN")
+                        cdf = soft.cumsum()
+                        cdf /= cdf[-1]
+                    cache[g] = (soft, cdf)
+                soft, cdf = cache[g]
+            if prio_pos:
+                pos[b] = cdf.searchsorted(u[b], side="right")
+            else:
+                pos[b] = self.rng.randint(0, self.lengths[g] - 1)
+            if self.uses_priority:
+                mouve[b] = soft[pos[b]]
+        game_pos = np.stack([gi, pos], 1)
+        row_pos = np.stack([self.rows[gi], pos], 1).astype(np.int32)
+        if self.uses_priority:
+            priority = self.soft_prio_game[gi] * mouve
+            ratio = 1 / (self.big_n_of_importance_sampling_ratio * priority)
+            return row_pos, ratio, game_pos
+        return row_pos, np.array([0]), game_pos
+
+    def update_value(self, new_value, position):
+        """update_value (replay_buffer.py:169-177); new_value [K][B] or [K][B][1]."""
+        nv = np.asarray(new_value, np.float64)
+        nv = nv.reshape(nv.shape[0], nv.shape[1])
+        pp = self.prio_position
+        for count, (g, p) in enumerate(np.asarray(position, np.int64)):
+            hi = min(self.num_unroll + p, self.lengths[g] - 1)
+            row = pp[g]
+            if hi > p:
+                row[p:hi] = nv[: hi - p, count]
+            self.prio_game[g] = np.max(row)
+
+
+# ---------------------------------------------------------------------------- device arena
+class Arena:
+    """Owner of one mzs_arena (include/mzsearch.h): G environment slots + trajectory rows in HBM."""
+
+    ARRAYS = dict(length=(_lib.ARENA_LENGTH, "<i4"), obs=(_lib.ARENA_OBS, "<f4"),
+                  action=(_lib.ARENA_ACTION, "<i4"), reward=(_lib.ARENA_REWARD, "<f4"),
+                  root_value=(_lib.ARENA_ROOT_VALUE, "<f4"), policy=(_lib.ARENA_POLICY, "<f4"),
+                  alive=(_lib.ARENA_ALIVE, "<i4"), state=(_lib.ARENA_STATE, "<f8"),
+                  stream_seed=(_lib.ARENA_STREAM_SEED, "<i8"), slot_row=(_lib.ARENA_SLOT_ROW, "<i4"))
+
+    def __init__(self, engine, n_slots, n_rows=None, max_moves=500, env=_lib.ENV_CARTPOLE):
+        self.eng, self.lib = engine, engine.lib
+        self.G, self.T = int(n_slots), int(max_moves)
+        self.n_rows = int(n_rows) if n_rows is not None else self.G
+        if self.G > engine.max_games:
+            raise ValueError(f"{self.G} slots exceed the engine's max_games {engine.max_games}")
+        cfg = _lib.ArenaConfig(engine.device.index, int(env), self.G, self.n_rows, self.T)
+        h = C.c_void_p()
+        _lib.check(self.lib.mzs_arena_create(C.byref(cfg), C.byref(h)), "mzs_arena_create")
+        self.h = h
+        self.obs_dim = int(self.lib.mzs_arena_obs_dim(h))
+        self.A = int(self.lib.mzs_arena_n_actions(h))
+        if (self.obs_dim, self.A) != (engine.obs_dim, engine.A):
+            raise ValueError(f"environment is obs {self.obs_dim} / {self.A} actions, the model "
+                             f"{engine.obs_dim} / {engine.A}")
+        dev = engine.device
+        self.obs = torch.zeros((self.G, self.obs_dim), dtype=torch.float32, device=dev)
+        self.alive_count = torch.zeros(1, dtype=torch.int32, device=dev)
+        shapes = dict(length=(self.n_rows,), obs=(self.n_rows, self.T, self.obs_dim),
+                      action=(self.n_rows, self.T), reward=(self.n_rows, self.T),
+                      root_value=(self.n_rows, self.T), policy=(self.n_rows, self.T, self.A),
+                      alive=(self.G,), state=(self.G, 4), stream_seed=(self.G,), slot_row=(self.G,))
+        self.arrays = {}
+        for k, (which, ts) in self.ARRAYS.items():
+            p = self.lib.mzs_arena_array(h, which)
+            self.arrays[k] = torch.as_tensor(_DevView(p, shapes[k], ts), device=dev)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.mzs_arena_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def begin(self, row0, seeds, episode):
+        """Start a round of len(seeds) games recorded in rows [row0, row0 + len(seeds)): the first
+        G start now, the others as slots free up.  Returns the device observation tensor
+        [G, obs_dim] that the moves keep updating in place."""
+        seeds = self.eng._dev(np.asarray(seeds, np.int64) if not torch.is_tensor(seeds) else seeds, torch.int64)
+        n = int(seeds.shape[0])
+        if seeds.dim() != 1 or n < 1 or row0 < 0 or row0 + n > self.n_rows:
+            raise ValueError(f"{n} games from row {row0} do not fit {self.n_rows} rows")
+        self.seeds, self.episode, self.n_games = seeds, int(episode), n
+        _lib.check(self.lib.mzs_arena_begin(self.h, int(row0), n, _ptr(seeds), int(episode), _ptr(self.obs),
+                                            self.eng._stream()), "mzs_arena_begin")
+        return self.obs
+
+    def step(self, temperature, results=None):
+        """One move of every live slot from the engine's latest search results."""
+        r = self.eng.results_view() if results is None else results
+        if r["visits"].shape != (self.G, self.A):
+            raise ValueError("the last search did not cover every slot")
+        _lib.check(self.lib.mzs_arena_step(self.h, _ptr(r["visits"]), _ptr(r["root_value"]),
+                                           _ptr(r["root_prior"]), float(temperature), _ptr(self.obs),
+                                           _ptr(self.alive_count), self.eng._stream()), "mzs_arena_step")
+
+    def priority(self, row0, n_rows, td_steps, discount, longest):
+        """Game.make_priority for rows [row0, row0 + n_rows) on the device: float64 tensor
+        [n_rows, longest] (longest = the longest game among those rows)."""
+        dev = self.eng.device
+        dp_d = torch.as_tensor(discount_powers(discount, int(td_steps))).to(dev)
+        stride = max(1, min(int(longest), self.T))
+        out = torch.empty((int(n_rows), stride), dtype=torch.float64, device=dev)
+        self._keep_p = dp_d
+        _lib.check(self.lib.mzs_arena_priority(self.h, int(row0), int(n_rows), int(td_steps), _ptr(dp_d), stride,
+                                               _ptr(out), self.eng._stream()), "mzs_arena_priority")
+        return out
+
+    def make_batch(self, row_pos, num_unroll, td_steps, discount):
+        """ReplayBuffer.sample_batch's gather + Game.make_target on the device, in the layout
+        muzero_amd.train.Trainer.grad_step takes: obs [B, obs], actions [K, B, A], target value /
+        reward [K, B], target policy [K, B, A]."""
+        rp = np.ascontiguousarray(row_pos, np.int32)
+        B, K = rp.shape[0], int(num_unroll)
+        if rp.ndim != 2 or rp.shape[1] != 2:
+            raise ValueError("row_pos must be [B, 2]")
+        if B and (rp[:, 0].min() < 0 or rp[:, 0].max() >= self.n_rows or rp[:, 1].min() < 0 or
+                  rp[:, 1].max() >= self.T):
+            raise ValueError("row_pos out of range")
+        dev = self.eng.device
+        rp_d = torch.as_tensor(rp).to(dev)
+        dp_d = torch.as_tensor(discount_powers(discount, int(td_steps))).to(dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        obs, actions = torch.empty((B, self.obs_dim), **f32), torch.empty((K, B, self.A), **f32)
+        tv, tr, tp = torch.empty((K, B), **f32), torch.empty((K, B), **f32), torch.empty((K, B, self.A), **f32)
+        self._keep = (rp_d, dp_d)
+        _lib.check(self.lib.mzs_arena_make_batch(self.h, B, _ptr(rp_d), K, int(td_steps), _ptr(dp_d), _ptr(obs),
+                                                 _ptr(actions), _ptr(tv), _ptr(tr), _ptr(tp),
+                                                 self.eng._stream()), "mzs_arena_make_batch")
+        return obs, actions, tv, tr, tp
+
+
+def play_round(engine, arena, seeds, episode, num_simulations, temperature, row0=0, check_every=16,
+               train=True):
+    """learning_cycle's self-play phase (self_play.py:230-236: len(seeds) play_game calls, each the
+    loop of self_play.py:62-73) on arena.G slots at once.  Returns the number of lock-step moves.
+    Everything between the alive checks is enqueued without a host sync."""
+    obs = arena.begin(row0, seeds, episode)
+    S = int(num_simulations)
+    moves = 0
+    for _ in range(arena.n_games * arena.T):
+        dirichlet, noise = engine.fill_streams(arena.arrays["stream_seed"], S, train)
+        engine.search(obs, dirichlet, noise if S > 0 else None, S, train)
+        arena.step(temperature)
+        moves += 1
+        if moves % check_every == 0 and int(arena.alive_count.item()) == 0:
+            break
+    return moves
+
+
+class SelfPlay:
+    """learning_cycle (self_play.py:144-281) with batched self-play: every iteration plays
+    `games_per_iteration` (number_of_self_play_before_training) episodes on arena.G slots, saves
+    them in the ReplayStore in game order and runs the training steps on the same GPU, same weights."""
+
+    def __init__(self, muzero, engine, trainer, arena, store, num_simulations, games_per_iteration=None,
+                 seed=0):
+        self.mz, self.eng, self.trainer, self.arena, self.store = muzero, engine, trainer, arena, store
+        self.S = int(num_simulations)
+        self.N = int(games_per_iteration) if games_per_iteration else arena.G
+        self.seed = int(seed)
+        self.block = 0
+        self.episode = 0
+        self.n_blocks = arena.n_rows // self.N
+        need = -(-(store.window_size + 1) // self.N) + 1
+        if self.n_blocks < need:
+            raise ValueError(f"arena needs {need * self.N} rows for a window of {store.window_size} games "
+                             f"played {self.N} per iteration (has {arena.n_rows})")
+
+    def play(self, temperature):
+        """One round of N games into the next block of rows; returns their total rewards."""
+        a, N = self.arena, self.N
+        row0 = self.block * N
+        seeds = (np.arange(N, dtype=np.int64) * 2654435761 + self.seed) & 0x7FFFFFFF
+        self.lockstep_moves = play_round(self.eng, a, seeds, self.episode, self.S, temperature, row0)
+        lengths_d = a.arrays["length"][row0:row0 + N]
+        lengths = lengths_d.cpu().numpy()
+        longest = int(lengths.max())
+        prio = None
+        if self.store.uses_priority:
+            prio = a.priority(row0, N, self.store.td_steps, self.store.discount, longest).cpu().numpy()
+        self.store.save_games(np.arange(row0, row0 + N), lengths, priorities=prio)
+        self.block = (self.block + 1) % self.n_blocks
+        self.episode += 1
+        rw = a.arrays["reward"][row0:row0 + N, :longest]
+        mask = torch.arange(longest, device=rw.device)[None, :] < lengths_d[:, None]
+        return (rw * mask).sum(1).cpu().numpy()                       # sum(g.rewards), self_play.py:240
+
+    def train_step(self):
+        """sample_batch -> make_batch -> Muzero.train -> update_value (self_play.py:259-262)."""
+        st = self.store
+        row_pos, ratio, game_pos = st.sample_batch()
+        obs, actions, tv, tr, tp = self.arena.make_batch(row_pos, st.num_unroll, st.td_steps, st.discount)
+        isr = None if np.size(ratio) == 1 else np.asarray(ratio, np.float32)
+        prio = self.trainer.step(obs, actions, tv, tr, tp, isr)
+        loss = self.trainer.loss[-1].clone()        # loss_nn (muzero_model.py:734), still on the device
+        if st.uses_priority:
+            st.update_value(prio.detach().cpu().numpy(), game_pos)
+        return loss
+
+    def learning_cycle(self, number_of_iteration, number_of_training_before_self_play=1,
+                       temperature_type="static_temperature", verbose=False):
+        rewards, losses = [], []
+        for ep in range(1, number_of_iteration + 1):
+            t = temperature_scheduler(number_of_iteration + 1, ep, temperature_type)
+            rewards.append(float(np.mean(self.play(t))))
+            cache = [self.train_step() for _ in range(number_of_training_before_self_play)]
+            losses.append(float(torch.stack(cache).mean().item()))
+            if verbose:
+                print(f"EPOCH {ep} || selfplay reward: {rewards[-1]} || training loss: {losses[-1]}||")
+        return rewards, losses

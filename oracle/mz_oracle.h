@@ -106,6 +106,36 @@ int mzo_train_grad(const mzs_dims* d, const float* blob, const mzo_train_batch* 
 void mzo_adam_step(float* w, float* m, float* v, const float* g, size_t n, int step, double lr);
 void mzo_sgd_step(float* w, float* buf, const float* g, size_t n, int step, double lr);
 
+/* ---- self-play bookkeeping (oracle/mz_selfplay_oracle.c; pinned by tests/test_selfplay_oracle.py).
+ * Trajectory arrays are [n_rows][T]...; slots take rows as mzs_arena_begin / mzs_arena_step do. */
+void mzo_store_policy(int32_t A, const int32_t* visits, const double* prior, float* policy);
+int32_t mzo_policy_action(int32_t A, const int32_t* visits, double temperature, double u);
+double mzo_cartpole_step(double* state4, int32_t action, int32_t* terminated); /* returns the reward */
+typedef struct mzo_arena { /* arrays owned by the caller (oracle/mz_oracle.py) */
+    int32_t G, n_rows, T, A, episode, next_row, row_end;
+    double* state;        /* [G][4] */
+    int32_t* alive;       /* [G] */
+    int32_t* row;         /* [G] */
+    int64_t* stream_seed; /* [G] */
+    float* obs;           /* [G][4] */
+    int64_t* row_seed;    /* [n_rows] */
+    int32_t* length;      /* [n_rows] */
+    float* traj_obs;      /* [n_rows][T][4] */
+    int32_t* traj_action; /* [n_rows][T] */
+    float* traj_reward;   /* [n_rows][T] */
+    float* traj_root;     /* [n_rows][T] */
+    float* traj_policy;   /* [n_rows][T][A] */
+} mzo_arena;
+void mzo_arena_begin(mzo_arena* ar, int32_t row0, int32_t n_games, const int64_t* seeds, int32_t episode);
+int32_t mzo_arena_step(mzo_arena* ar, const int32_t* visits, const float* root_value, const double* root_prior,
+                       double temperature);
+void mzo_make_priority(int32_t n_rows, int32_t T, const int32_t* length, const float* traj_reward,
+                       const float* traj_root, int32_t td, const double* disc_pow, double* out);
+void mzo_make_batch(int32_t T, int32_t A, int32_t obs_dim, const int32_t* length, const float* traj_obs,
+                    const int32_t* traj_action, const float* traj_reward, const float* traj_root,
+                    const float* traj_policy, int32_t B, const int32_t* row_pos, int32_t K, int32_t td,
+                    const double* disc_pow, float* obs, float* actions, float* tv, float* tr, float* tp);
+
 #ifdef __cplusplus
 }
 #endif

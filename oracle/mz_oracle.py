@@ -40,7 +40,8 @@ class SearchOut(C.Structure):
 
 def build(force=False):
     so = os.path.join(_HERE, "libmzoracle.so")
-    srcs = [os.path.join(_HERE, f) for f in ("mz_oracle.c", "mz_train_oracle.c", "mz_oracle.h")]
+    srcs = [os.path.join(_HERE, f) for f in ("mz_oracle.c", "mz_train_oracle.c", "mz_selfplay_oracle.c",
+                                             "mz_oracle.h", "../include/mzs_env.h")]
     stale = os.path.exists(so) and all(os.path.exists(f) for f in srcs) and \
         os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs)
     if force or stale or not os.path.exists(so):
@@ -221,3 +222,96 @@ def sgd_step(w, buf, g, step, lr):
     f = lib().mzo_sgd_step
     f.restype = None
     f(_p(w), _p(buf), _p(_f32(g)), C.c_size_t(w.size), C.c_int(step), C.c_double(lr))
+
+
+# ------------------------------------------------------------------ self-play bookkeeping
+def store_policy(visits, prior):
+    v = np.ascontiguousarray(visits, np.int32)
+    pr = np.ascontiguousarray(prior, np.float64)
+    out = np.zeros(v.size, np.float32)
+    lib().mzo_store_policy(C.c_int32(v.size), _p(v), _p(pr), _p(out))
+    return out
+
+
+def policy_action(visits, temperature, u):
+    v = np.ascontiguousarray(visits, np.int32)
+    f = lib().mzo_policy_action
+    f.restype = C.c_int32
+    return int(f(C.c_int32(v.size), _p(v), C.c_double(temperature), C.c_double(u)))
+
+
+def cartpole_step(state, action):
+    s = np.array(state, np.float64)
+    term = C.c_int32(0)
+    f = lib().mzo_cartpole_step
+    f.restype = C.c_double
+    r = f(_p(s), C.c_int32(action), C.byref(term))
+    return s, float(r), bool(term.value)
+
+
+class _Arena(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("G", "n_rows", "T", "A", "episode", "next_row", "row_end")] + \
+               [(n, C.c_void_p) for n in ("state", "alive", "row", "stream_seed", "obs", "row_seed", "length",
+                                          "traj_obs", "traj_action", "traj_reward", "traj_root", "traj_policy")]
+
+
+class ArenaOracle:
+    """G slots / n_rows trajectory rows on the CPU: the arrays the device arena keeps."""
+
+    def __init__(self, G, T, A=2, obs_dim=4, n_rows=None):
+        R = G if n_rows is None else n_rows
+        self.G, self.T, self.A, self.obs_dim, self.n_rows = G, T, A, obs_dim, R
+        self.state = np.zeros((G, 4), np.float64)
+        self.alive = np.zeros(G, np.int32)
+        self.row = np.zeros(G, np.int32)
+        self.stream_seed = np.zeros(G, np.int64)
+        self.obs = np.zeros((G, obs_dim), np.float32)
+        self.row_seed = np.zeros(R, np.int64)
+        self.length = np.zeros(R, np.int32)
+        self.traj_obs = np.zeros((R, T, obs_dim), np.float32)
+        self.traj_action = np.zeros((R, T), np.int32)
+        self.traj_reward = np.zeros((R, T), np.float32)
+        self.traj_root = np.zeros((R, T), np.float32)
+        self.traj_policy = np.zeros((R, T, A), np.float32)
+        self.c = _Arena(G, R, T, A, 0, 0, 0, *(a.ctypes.data for a in (
+            self.state, self.alive, self.row, self.stream_seed, self.obs, self.row_seed, self.length,
+            self.traj_obs, self.traj_action, self.traj_reward, self.traj_root, self.traj_policy)))
+
+    def begin(self, seeds, episode, row0=0):
+        seeds = np.ascontiguousarray(seeds, np.int64)
+        assert row0 + len(seeds) <= self.n_rows
+        lib().mzo_arena_begin(C.byref(self.c), C.c_int32(row0), C.c_int32(len(seeds)), _p(seeds), C.c_int32(episode))
+        return self.obs
+
+    def step(self, visits, root_value, root_prior, temperature):
+        v = np.ascontiguousarray(visits, np.int32)
+        rv = _f32(root_value)
+        rp = np.ascontiguousarray(root_prior, np.float64)
+        f = lib().mzo_arena_step
+        f.restype = C.c_int32
+        return f(C.byref(self.c), _p(v), _p(rv), _p(rp), C.c_double(temperature))
+
+
+def make_batch(length, traj_obs, traj_action, traj_reward, traj_root, traj_policy, row_pos, K, td, disc_pow):
+    T, A, obs_dim = traj_obs.shape[1], traj_policy.shape[2], traj_obs.shape[2]
+    rp = np.ascontiguousarray(row_pos, np.int32)
+    B = rp.shape[0]
+    dp = np.ascontiguousarray(disc_pow, np.float64)
+    obs = np.zeros((B, obs_dim), np.float32)
+    actions = np.zeros((K, B, A), np.float32)
+    tv, tr = np.zeros((K, B), np.float32), np.zeros((K, B), np.float32)
+    tp = np.zeros((K, B, A), np.float32)
+    lib().mzo_make_batch(C.c_int32(T), C.c_int32(A), C.c_int32(obs_dim), _p(np.ascontiguousarray(length, np.int32)),
+                         _p(_f32(traj_obs)), _p(np.ascontiguousarray(traj_action, np.int32)), _p(_f32(traj_reward)),
+                         _p(_f32(traj_root)), _p(_f32(traj_policy)), C.c_int32(B), _p(rp), C.c_int32(K),
+                         C.c_int32(td), _p(dp), _p(obs), _p(actions), _p(tv), _p(tr), _p(tp))
+    return obs, actions, tv, tr, tp
+
+
+def make_priority(length, traj_reward, traj_root, td, disc_pow):
+    rw, rv = _f32(traj_reward), _f32(traj_root)
+    n, T = rv.shape
+    out = np.zeros((n, T), np.float64)
+    lib().mzo_make_priority(C.c_int32(n), C.c_int32(T), _p(np.ascontiguousarray(length, np.int32)), _p(rw), _p(rv),
+                            C.c_int32(td), _p(np.ascontiguousarray(disc_pow, np.float64)), _p(out))
+    return out

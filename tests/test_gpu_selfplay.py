@@ -1,0 +1,185 @@
+"""GPU parity of the batched self-play path (mzs_arena_* through the C-ABI) against the CPU oracle
+(oracle/mz_selfplay_oracle.c, itself pinned to the reference's Game / ReplayBuffer by
+tests/test_selfplay_oracle.py).  Integer / index work and the fp32 / fp64 targets: bit-exact."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TAG = "tag123"     # CartPole checkpoint shape: obs 4, 2 actions
+
+
+def make_engine(G, S, discount=0.997):
+    from muzero_amd.engine import SearchEngine
+    w = load_golden(f"weights_{TAG}.npz")
+    dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L"))
+    eng = SearchEngine(dims, max_games=G, max_simulations=S, discount=discount)
+    eng.set_weights(w["blob"])
+    return eng, dims, w["blob"]
+
+
+def host(t):
+    return t.cpu().numpy()
+
+
+def arena_host(ar, rows=None):
+    import torch
+    torch.cuda.synchronize()
+    out = {k: host(v) for k, v in ar.arrays.items()}
+    return out
+
+
+def fake_results(rs, G, A, dev, small=0.1):
+    import torch
+    visits = rs.multinomial(50, rs.dirichlet(np.ones(A)), G).astype(np.int32)
+    few = rs.random_sample(G) < small
+    visits[few] = rs.multinomial(2, np.ones(A) / A, int(few.sum()))
+    tie = rs.random_sample(G) < small
+    visits[tie] = 25
+    rv = rs.standard_normal(G).astype(np.float32) * 3
+    pr = rs.dirichlet(np.ones(A), G) * rs.uniform(0.5, 1.5, (G, 1))
+    res = dict(visits=torch.as_tensor(visits).to(dev), root_value=torch.as_tensor(rv).to(dev),
+               root_prior=torch.as_tensor(pr).to(dev))
+    return (visits, rv, pr), res
+
+
+@pytest.mark.parametrize("temperature", [0.0, 0.25, 0.5, 1.0, 0.7])
+def test_arena_step_vs_oracle(temperature):
+    import torch
+    from muzero_amd.selfplay import Arena
+    from oracle import mz_oracle as mzo
+    G, T = 300, 24
+    N = G if temperature != 1.0 else 3 * G + 17          # more games than slots: refill in slot order
+    R = N + 5
+    eng, dims, _ = make_engine(G, 0)
+    ar = Arena(eng, G, R, T)
+    orc = mzo.ArenaOracle(G, T, n_rows=R)
+    seeds = np.arange(N, dtype=np.int64) * 7919 + 5
+    obs = ar.begin(5, seeds, episode=3)
+    want = orc.begin(seeds, 3, row0=5)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(obs), want)
+    rs = np.random.RandomState(int(temperature * 100))
+    for t in range(N * T):
+        (v, rv, pr), res = fake_results(rs, G, 2, eng.device)
+        ar.step(temperature, res)
+        n_alive = orc.step(v, rv, pr, temperature)
+        torch.cuda.synchronize()
+        assert int(ar.alive_count.item()) == n_alive
+        assert np.array_equal(host(obs), orc.obs)
+        assert np.array_equal(host(ar.arrays["alive"]), orc.alive)
+        live = orc.alive == 1
+        assert np.array_equal(host(ar.arrays["slot_row"])[live], orc.row[live])
+        assert np.array_equal(host(ar.arrays["stream_seed"])[live], orc.stream_seed[live])
+        if n_alive == 0:
+            break
+    got = arena_host(ar)
+    assert np.array_equal(got["length"], orc.length)
+    assert np.array_equal(got["state"], orc.state)              # fp64 physics, bit for bit
+    for k, w in (("obs", orc.traj_obs), ("action", orc.traj_action), ("reward", orc.traj_reward),
+                 ("root_value", orc.traj_root), ("policy", orc.traj_policy)):
+        assert np.array_equal(got[k], w), k
+    assert n_alive == 0 and np.all(orc.length[5:] >= 1) and np.all(orc.length[:5] == 0)
+    ar.close(), eng.close()
+
+
+@pytest.mark.parametrize("td,K", [(3, 5), (10, 5), (50, 10)])
+def test_make_batch_vs_oracle(td, K):
+    import torch
+    from muzero_amd.selfplay import Arena, discount_powers
+    from oracle import mz_oracle as mzo
+    G, T = 128, 64
+    eng, dims, _ = make_engine(G, 0)
+    ar = Arena(eng, G, 2 * G, T)
+    rs = np.random.RandomState(td)
+    for block in range(2):                       # two blocks of rows, different seeds
+        ar.begin(block * G, np.arange(G, dtype=np.int64) + 1000 * block, episode=block)
+        for t in range(T):
+            _, res = fake_results(rs, G, 2, eng.device)
+            ar.step(1.0, res)
+        torch.cuda.synchronize()
+        assert int(ar.alive_count.item()) == 0
+    got = arena_host(ar)
+    assert got["length"].min() >= 1 and got["length"].max() <= T
+    B = 777
+    rows = rs.randint(0, 2 * G, B)
+    pos = np.array([rs.randint(0, got["length"][r]) for r in rows])
+    pos[:G] = got["length"][rows[:G]] - 1        # last position: mostly absorbing targets
+    row_pos = np.stack([rows, pos], 1).astype(np.int32)
+    out = ar.make_batch(row_pos, K, td, 0.997)
+    torch.cuda.synchronize()
+    want = mzo.make_batch(got["length"], got["obs"], got["action"], got["reward"], got["root_value"],
+                          got["policy"], row_pos, K, td, discount_powers(0.997, td))
+    for name, g, w in zip(("obs", "actions", "tv", "tr", "tp"), out, want):
+        assert np.array_equal(host(g), w), name
+    with pytest.raises(ValueError):
+        ar.make_batch(np.array([[2 * G, 0]]), K, td, 0.997)
+    # Game.make_priority on the device: full width and trimmed to the longest game
+    wantp = mzo.make_priority(got["length"], got["reward"], got["root_value"], td, discount_powers(0.997, td))
+    assert np.array_equal(host(ar.priority(0, 2 * G, td, 0.997, T)), wantp)
+    longest = int(got["length"][G:].max())
+    assert np.array_equal(host(ar.priority(G, G, td, 0.997, longest)), wantp[G:, :longest])
+    ar.close(), eng.close()
+
+
+def test_play_round_real_search_vs_oracle():
+    """The whole per-move loop on the GPU (fill_streams -> search -> arena step): the oracle arena,
+    fed with the same search results move by move, records identical trajectories."""
+    import torch
+    from muzero_amd.selfplay import Arena
+    from oracle import mz_oracle as mzo
+    G, T, S, N = 192, 40, 20, 500
+    eng, dims, _ = make_engine(G, S)
+    ar = Arena(eng, G, N, T)
+    orc = mzo.ArenaOracle(G, T, n_rows=N)
+    seeds = np.arange(N, dtype=np.int64) * 31 + 7
+    obs = ar.begin(0, seeds, 0)
+    orc.begin(seeds, 0)
+    for t in range(N * T):
+        dirichlet, noise = eng.fill_streams(ar.arrays["stream_seed"], S, True)
+        eng.search(obs, dirichlet, noise, S, True)
+        r = {k: host(v) for k, v in eng.results_view().items()}
+        torch.cuda.synchronize()
+        assert np.all(r["visits"].sum(1) == S)
+        ar.step(1.0)
+        n_alive = orc.step(r["visits"], r["root_value"], r["root_prior"], 1.0)
+        assert int(ar.alive_count.item()) == n_alive
+        if n_alive == 0:
+            break
+    got = arena_host(ar)
+    assert np.array_equal(got["length"], orc.length)
+    for k, w in (("obs", orc.traj_obs), ("action", orc.traj_action), ("root_value", orc.traj_root),
+                 ("policy", orc.traj_policy)):
+        assert np.array_equal(got[k], w), k
+    assert 8 <= got["length"].mean() <= T         # CartPole under a random-ish policy: 10-40 moves
+    ar.close(), eng.close()
+
+
+def test_play_round_helper_and_learning_cycle():
+    """learning_cycle end to end on one GPU: play, save, sample, gather, train; the search of the
+    next round reads the updated weights."""
+    import torch
+    from muzero_amd.selfplay import Arena, ReplayStore, SelfPlay
+    from muzero_amd.train import Trainer
+    G, T, S, B, K, td, N = 128, 48, 10, 64, 5, 10, 300
+    eng, dims, blob = make_engine(G, S)
+    tr = Trainer(eng, K, B, "adam", 1e-3)
+    store = ReplayStore(window_size=2 * N, batch_size=B, num_unroll=K, td_steps=td, discount=0.997)
+    ar = Arena(eng, G, 4 * N, T)
+    np.random.seed(0)
+    loop = SelfPlay(None, eng, tr, ar, store, S, games_per_iteration=N, seed=42)
+    rewards, losses = loop.learning_cycle(4, number_of_training_before_self_play=3,
+                                          temperature_type="static_one_temperature")
+    assert len(rewards) == 4 and all(1 <= r <= T for r in rewards)
+    assert all(np.isfinite(l) and l > 0 for l in losses)
+    assert len(store) == 2 * N + 1                                  # the reference's window rule
+    assert store.big_n_of_importance_sampling_ratio == sum(store.lengths)
+    assert not np.array_equal(tr.weights(), blob)
+    # rows of the store are live arena rows with matching lengths
+    length = host(ar.arrays["length"])
+    assert all(length[r] == n for r, n in zip(store.rows, store.lengths))
+    with pytest.raises(ValueError):
+        SelfPlay(None, eng, tr, Arena(eng, G, 2 * N, T), store, S, N)   # too few rows for the window
+    ar.close(), eng.close()

@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Throughput of the batched self-play loop on one MI355X: G games x S simulations per move,
+fill_streams -> search -> arena step per move, then sample / gather / train steps.
+Prints one JSON line.  Usage: python tools/bench_selfplay.py [--games 4096] [--sims 50]"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from muzero_amd.engine import SearchEngine  # noqa: E402
+from muzero_amd.selfplay import Arena, ReplayStore, SelfPlay, play_round  # noqa: E402
+from muzero_amd.train import Trainer  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--games", type=int, default=4096)
+    ap.add_argument("--sims", type=int, default=50)
+    ap.add_argument("--max-moves", type=int, default=500)
+    ap.add_argument("--rounds", type=int, default=3)
+    ap.add_argument("--games-per-round", type=int, default=0, help="default 8 x --games")
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--train-steps", type=int, default=50)
+    a = ap.parse_args()
+    G, S, T = a.games, a.sims, a.max_moves
+    dims = (4, 2, 31, 64, 0)
+    eng = SearchEngine(dims, max_games=G, max_simulations=S, discount=0.997)
+    n = eng.weight_count()
+    eng.set_weights((np.random.RandomState(0).standard_normal(n) * 0.1).astype(np.float32))
+    K, td = 5, 10
+    tr = Trainer(eng, K, a.batch, "adam", 1e-3)
+    N = a.games_per_round or 8 * G
+    store = ReplayStore(window_size=N, batch_size=a.batch, num_unroll=K, td_steps=td, discount=0.997)
+    ar = Arena(eng, G, 3 * N, T)
+    loop = SelfPlay(None, eng, tr, ar, store, S, games_per_iteration=N, seed=1)
+    np.random.seed(0)
+    out = []
+    for r in range(a.rounds):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if r == a.rounds - 1:          # last round: time the device loop alone
+            seeds = (np.arange(N, dtype=np.int64) * 2654435761 + 99) & 0x7FFFFFFF
+            mv = play_round(eng, ar, seeds, 1000 + r, S, 1.0, loop.block * N)
+            torch.cuda.synchronize()
+            tl = time.perf_counter() - t0
+            n_moves = int(ar.arrays["length"][loop.block * N:(loop.block + 1) * N].sum().item())
+            out.append(dict(loop_only=True, loop_s=tl, loop_moves=mv, ms_per_lockstep_move=tl * 1e3 / mv,
+                            game_moves=n_moves, sims_per_s=n_moves * S / tl))
+            t0 = time.perf_counter()
+        rewards = loop.play(1.0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        moves = int(rewards.sum())
+        longest = loop.lockstep_moves
+        for _ in range(a.train_steps):
+            loss = loop.train_step()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        out.append(dict(round=r, play_s=t1 - t0, game_moves=moves, longest=longest,
+                        moves_per_s=moves / (t1 - t0), slot_utilisation=moves / (longest * G),
+                        sims_per_s=moves * S / (t1 - t0), search_sims_per_s=longest * G * S / (t1 - t0), train_ms_per_step=(t2 - t1) * 1e3 / a.train_steps,
+                        mean_reward=float(rewards.mean()), loss=float(loss.item())))
+    print(json.dumps(dict(games_per_round=N, slots=G, sims=S, max_moves=T, batch=a.batch, rounds=out)))
+
+
+if __name__ == "__main__":
+    main()
