@@ -213,13 +213,15 @@ int mzs_arena_begin(mzs_arena* arena, int32_t row0, int32_t n_games, const int64
 /* One move of every live slot, fed with this move's search results (mzs_results layout):
  * Game.store_search_statistics (game.py:154-168), Game.policy_step (game.py:176-225: temperature
  * rescale, np.random.choice above temperature 0.1 else argmax, env.step, append to the lists);
+ * num_simulations = the search's simulation count: with 0 the policy handed to policy_step is the
+ * root priors instead of the visit counts (monte_carlo_tree_search.py:218-221);
  * then free slots take the round's next unplayed games in slot order.  obs_dev is overwritten
  * with the next observations (the reset observation for a newly started game);
  * *alive_count_dev = slots with a running game afterwards (0: the round is complete — play_game's
  * loop condition, self_play.py:62, has ended every game).  MZS_ARENA_STREAM_SEED holds, per slot,
  * the seed of the RandomState stream its next search draws from (mzs_fill_streams). */
 int mzs_arena_step(mzs_arena* arena, const int32_t* visits_dev, const float* root_value_dev,
-                   const double* root_prior_dev, double temperature, float* obs_dev,
+                   const double* root_prior_dev, double temperature, int32_t num_simulations, float* obs_dev,
                    int32_t* alive_count_dev, void* stream);
 
 /* ReplayBuffer.sample_batch's per-sample work (replay_buffer.py:147-151: make_image,

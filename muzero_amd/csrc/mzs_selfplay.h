@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) k_arena_begin(const ArenaArrays a, int ro
  * visits / root_value / root_prior are the search results of this move (mzs_results layout). */
 __global__ void __launch_bounds__(256) k_arena_step(const ArenaArrays a, const int* visits,
                                                     const float* root_value, const double* root_prior,
-                                                    double temperature, float* obs_io) {
+                                                    double temperature, int from_prior, float* obs_io) {
     const int g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g >= a.G || !a.alive[g]) return;
     const int A = a.A, row = a.row[g], t = a.length[row];
@@ -107,32 +107,38 @@ __global__ void __launch_bounds__(256) k_arena_step(const ArenaArrays a, const i
         for (int i = 0; i < A; ++i) pol[i] = (float)(root_prior[(size_t)g * A + i] / psum);
     }
     a.root_value[(size_t)row * a.T + t] = root_value[g];
-    /* policy_step: softmax_stable(visit counts, temperature), then choice or argmax */
+    /* policy_step: softmax_stable(policy, temperature), then choice or argmax; the policy is what
+     * MCTS.run returns: visit counts, or the root priors when num_simulations == 0
+     * (monte_carlo_tree_search.py:218-221) */
+    const double* pr = root_prior + (size_t)g * A;
+    const double p0 = from_prior ? pr[0] : (double)v[0];
     double tsum = 0.0;
     bool all_equal = true;
     for (int i = 0; i < A; ++i) {
-        tsum += mzs_policy_power((double)v[i], temperature);
-        all_equal = all_equal && v[i] == v[0];
+        const double pi = from_prior ? pr[i] : (double)v[i];
+        tsum += mzs_policy_power(pi, temperature);
+        all_equal = all_equal && pi == p0;
     }
     int act = 0;
     if (temperature > 0.1 || all_equal) {
         /* np.random.choice(action, p): cdf = cumsum(p); cdf /= cdf[-1]; searchsorted(u, 'right') */
         const double u = mzs_uniform01((uint64_t)a.seed[g], (uint32_t)a.episode[g], (uint32_t)t, MZS_RNG_ACTION);
         double cl = 0.0;
-        for (int i = 0; i < A; ++i) cl += mzs_policy_power((double)v[i], temperature) / tsum;
+        for (int i = 0; i < A; ++i)
+            cl += mzs_policy_power(from_prior ? pr[i] : (double)v[i], temperature) / tsum;
         double c = 0.0;
         act = A - 1;
         for (int i = 0; i < A; ++i) {
-            c += mzs_policy_power((double)v[i], temperature) / tsum;
+            c += mzs_policy_power(from_prior ? pr[i] : (double)v[i], temperature) / tsum;
             if (u < c / cl) {
                 act = i;
                 break;
             }
         }
     } else {
-        double best = mzs_policy_power((double)v[0], temperature) / tsum;
+        double best = mzs_policy_power(p0, temperature) / tsum;
         for (int i = 1; i < A; ++i) {
-            const double p = mzs_policy_power((double)v[i], temperature) / tsum;
+            const double p = mzs_policy_power(from_prior ? pr[i] : (double)v[i], temperature) / tsum;
             if (p > best) best = p, act = i; /* np.argmax: first maximum */
         }
     }

@@ -1447,14 +1447,14 @@ int mzs_arena_begin(mzs_arena* ar, int32_t row0, int32_t n_games, const int64_t*
 }
 
 int mzs_arena_step(mzs_arena* ar, const int32_t* visits_dev, const float* root_value_dev,
-                   const double* root_prior_dev, double temperature, float* obs_dev, int32_t* alive_count_dev,
-                   void* stream) {
+                   const double* root_prior_dev, double temperature, int32_t num_simulations, float* obs_dev,
+                   int32_t* alive_count_dev, void* stream) {
     if (!ar || !visits_dev || !root_value_dev || !root_prior_dev || !obs_dev || !alive_count_dev)
         return fail(MZS_E_ARG, "null argument");
     HIP_TRY(hipSetDevice(ar->cfg.device));
     hipStream_t st = static_cast<hipStream_t>(stream);
     hipLaunchKernelGGL(k_arena_step, dim3((ar->a.G + 255) / 256), dim3(256), 0, st, ar->a, visits_dev,
-                       root_value_dev, root_prior_dev, temperature, obs_dev);
+                       root_value_dev, root_prior_dev, temperature, num_simulations < 1 ? 1 : 0, obs_dev);
     hipLaunchKernelGGL(k_arena_refill, dim3(1), dim3(kRefillThreads), 0, st, ar->a, obs_dev, alive_count_dev);
     HIP_TRY(hipGetLastError());
     return MZS_OK;

@@ -308,13 +308,15 @@ class Arena:
                                             self.eng._stream()), "mzs_arena_begin")
         return self.obs
 
-    def step(self, temperature, results=None):
-        """One move of every live slot from the engine's latest search results."""
+    def step(self, temperature, results=None, num_simulations=None):
+        """One move of every live slot from the engine's latest search results (num_simulations:
+        the simulation count of that search; 0 makes policy_step use the root priors)."""
+        S = self.eng.num_simulations if num_simulations is None else int(num_simulations)
         r = self.eng.results_view() if results is None else results
         if r["visits"].shape != (self.G, self.A):
             raise ValueError("the last search did not cover every slot")
         _lib.check(self.lib.mzs_arena_step(self.h, _ptr(r["visits"]), _ptr(r["root_value"]),
-                                           _ptr(r["root_prior"]), float(temperature), _ptr(self.obs),
+                                           _ptr(r["root_prior"]), float(temperature), S, _ptr(self.obs),
                                            _ptr(self.alive_count), self.eng._stream()), "mzs_arena_step")
 
     def priority(self, row0, n_rows, td_steps, discount, longest):
@@ -389,6 +391,62 @@ class SelfPlay:
         if self.n_blocks < need:
             raise ValueError(f"arena needs {need * self.N} rows for a window of {store.window_size} games "
                              f"played {self.N} per iteration (has {arena.n_rows})")
+
+    @classmethod
+    def from_config(cls, cfg, n_slots=None, games_per_iteration=None, window_size=None, seed=0, device=0,
+                    weights=None):
+        """Build engine, trainer, arena and store from a reference experiment config
+        (config/experiment_*.json as muzero_cli.py:48-114 consumes it; muzero_amd.config.load_config).
+        Every shipped config is CartPole-v1 + mlp_model.  The reference plays
+        `number_of_self_play_before_training` games (1 or 10) per iteration; pass
+        games_per_iteration / n_slots (or the optional "mi355x" section) to fill the GPU, and a
+        window_size to match, since the config's replay window (500 games) is sized for that."""
+        from .config import engine_id
+        from .engine import SearchEngine
+        from .model import Muzero
+        from .train import Trainer
+        if cfg["game"]["env"] != "CartPole-v1":
+            raise NotImplementedError(f"arena environment {cfg['game']['env']!r}: only CartPole-v1 "
+                                      "(include/mzs_env.h); other Gym environments go through the "
+                                      "drop-in Monte_carlo_tree_search.run, stepped on the host")
+        m, rb, mc, gp, lc = (cfg[k] for k in ("muzero", "replaybuffer", "monte_carlo_tree_search", "gameplay",
+                                              "learning_cycle"))
+        extra = cfg.get("mi355x", {})
+        N = int(games_per_iteration or extra.get("games_per_iteration") or lc["number_of_self_play_before_training"])
+        G = min(int(n_slots or extra.get("concurrent_games", 4096)), N)
+        W = int(window_size or extra.get("window_size") or rb["window_size"])
+        S = int(lc["number_of_mcts_simulation"])
+        mz = Muzero(model_structure=m["model_structure"], observation_space_dimensions=4,
+                    action_space_dimensions=2, state_space_dimensions=m["state_space_dimensions"],
+                    k_hypothetical_steps=m["k_hypothetical_steps"], learning_rate=m["learning_rate"],
+                    optimizer=m["optimizer"], lr_scheduler=m["lr_scheduler"], loss_type=m["loss_type"],
+                    num_of_epoch=m["num_of_epoch"], hidden_layer_dimensions=m["hidden_layer_dimensions"],
+                    number_of_hidden_layer=m["number_of_hidden_layer"], bin_method=m["bin_method"],
+                    bin_decomposition_number=m["bin_decomposition_number"])
+        if weights is not None:
+            mz.set_weights(weights)
+        eng = SearchEngine(mz.dims, max_games=G, max_simulations=S, discount=mc["discount"],
+                           root_exploration_fraction=mc["root_exploration_fraction"], pb_c_base=mc["pb_c_base"],
+                           pb_c_init=mc["pb_c_init"], root_dirichlet_alpha=mc["root_dirichlet_alpha"],
+                           device=device, engine=engine_id(cfg) if "mi355x" in cfg else _lib.ENGINE_FUSED)
+        eng.set_weights(mz.weights_blob())
+        mz._engine = eng
+        trainer = Trainer(eng, m["k_hypothetical_steps"], rb["batch_size"], m["optimizer"], m["learning_rate"],
+                          m["lr_scheduler"], m["num_of_epoch"])
+        mz._trainer = trainer
+        store = ReplayStore(W, rb["batch_size"], m["k_hypothetical_steps"], rb["td_steps"], rb["game_sampling"],
+                            rb["position_sampling"], discount=gp["discount"])
+        n_blocks = -(-(W + 1) // N) + 1
+        arena = Arena(eng, G, n_blocks * N, gp["limit_of_game_play"])
+        loop = cls(mz, eng, trainer, arena, store, S, games_per_iteration=N, seed=seed)
+        loop.cfg = cfg
+        return loop
+
+    def run_config(self, number_of_iteration=None, verbose=False):
+        """learning_cycle with the config's own iteration counts and temperature schedule."""
+        lc = self.cfg["learning_cycle"]
+        return self.learning_cycle(int(number_of_iteration or lc["number_of_iteration"]),
+                                   lc["number_of_training_before_self_play"], lc["tempererature_type"], verbose)
 
     def play(self, temperature):
         """One round of N games into the next block of rows; returns their total rewards."""

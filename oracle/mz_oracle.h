@@ -109,7 +109,7 @@ void mzo_sgd_step(float* w, float* buf, const float* g, size_t n, int step, doub
 /* ---- self-play bookkeeping (oracle/mz_selfplay_oracle.c; pinned by tests/test_selfplay_oracle.py).
  * Trajectory arrays are [n_rows][T]...; slots take rows as mzs_arena_begin / mzs_arena_step do. */
 void mzo_store_policy(int32_t A, const int32_t* visits, const double* prior, float* policy);
-int32_t mzo_policy_action(int32_t A, const int32_t* visits, double temperature, double u);
+int32_t mzo_policy_action(int32_t A, const double* policy, double temperature, double u);
 double mzo_cartpole_step(double* state4, int32_t action, int32_t* terminated); /* returns the reward */
 typedef struct mzo_arena { /* arrays owned by the caller (oracle/mz_oracle.py) */
     int32_t G, n_rows, T, A, episode, next_row, row_end;
@@ -128,7 +128,7 @@ typedef struct mzo_arena { /* arrays owned by the caller (oracle/mz_oracle.py) *
 } mzo_arena;
 void mzo_arena_begin(mzo_arena* ar, int32_t row0, int32_t n_games, const int64_t* seeds, int32_t episode);
 int32_t mzo_arena_step(mzo_arena* ar, const int32_t* visits, const float* root_value, const double* root_prior,
-                       double temperature);
+                       double temperature, int32_t from_prior);
 void mzo_make_priority(int32_t n_rows, int32_t T, const int32_t* length, const float* traj_reward,
                        const float* traj_root, int32_t td, const double* disc_pow, double* out);
 void mzo_make_batch(int32_t T, int32_t A, int32_t obs_dim, const int32_t* length, const float* traj_obs,

@@ -233,8 +233,8 @@ def store_policy(visits, prior):
     return out
 
 
-def policy_action(visits, temperature, u):
-    v = np.ascontiguousarray(visits, np.int32)
+def policy_action(policy, temperature, u):
+    v = np.ascontiguousarray(policy, np.float64)
     f = lib().mzo_policy_action
     f.restype = C.c_int32
     return int(f(C.c_int32(v.size), _p(v), C.c_double(temperature), C.c_double(u)))
@@ -283,13 +283,13 @@ class ArenaOracle:
         lib().mzo_arena_begin(C.byref(self.c), C.c_int32(row0), C.c_int32(len(seeds)), _p(seeds), C.c_int32(episode))
         return self.obs
 
-    def step(self, visits, root_value, root_prior, temperature):
+    def step(self, visits, root_value, root_prior, temperature, from_prior=False):
         v = np.ascontiguousarray(visits, np.int32)
         rv = _f32(root_value)
         rp = np.ascontiguousarray(root_prior, np.float64)
         f = lib().mzo_arena_step
         f.restype = C.c_int32
-        return f(C.byref(self.c), _p(v), _p(rv), _p(rp), C.c_double(temperature))
+        return f(C.byref(self.c), _p(v), _p(rv), _p(rp), C.c_double(temperature), C.c_int32(int(from_prior)))
 
 
 def make_batch(length, traj_obs, traj_action, traj_reward, traj_root, traj_policy, row_pos, K, td, disc_pow):

@@ -37,9 +37,10 @@ void mzo_store_policy(int32_t A, const int32_t* v, const double* prior, float* p
     }
 }
 
-/* Game.policy_step's action (game.py:184-188) from the visit counts MCTS.run returns
- * (monte_carlo_tree_search.py:219) and the uniform number np.random.choice would draw */
-int32_t mzo_policy_action(int32_t A, const int32_t* v, double temperature, double u) {
+/* Game.policy_step's action (game.py:184-188) from the policy MCTS.run returns (the visit
+ * counts, or the root priors when num_simulations == 0: monte_carlo_tree_search.py:218-221)
+ * and the uniform number np.random.choice would draw */
+int32_t mzo_policy_action(int32_t A, const double* v, double temperature, double u) {
     double tsum = 0.0;
     int all_equal = 1;
     for (int i = 0; i < A; ++i) {
@@ -105,7 +106,7 @@ void mzo_arena_begin(mzo_arena* ar, int32_t row0, int32_t n_games, const int64_t
 /* one move of every live slot, then free slots take the next unplayed games in slot order;
  * returns the number of slots with a running game */
 int32_t mzo_arena_step(mzo_arena* ar, const int32_t* visits, const float* root_value, const double* root_prior,
-                       double temperature) {
+                       double temperature, int32_t from_prior) {
     const int T = ar->T, A = ar->A;
     for (int g = 0; g < ar->G; ++g) {
         if (!ar->alive[g]) continue;
@@ -114,7 +115,9 @@ int32_t mzo_arena_step(mzo_arena* ar, const int32_t* visits, const float* root_v
         mzo_store_policy(A, v, root_prior + (size_t)g * A, ar->traj_policy + ((size_t)row * T + t) * A);
         ar->traj_root[(size_t)row * T + t] = root_value[g];
         const double u = mzs_uniform01((uint64_t)ar->row_seed[row], (uint32_t)ar->episode, (uint32_t)t, MZS_RNG_ACTION);
-        const int act = mzo_policy_action(A, v, temperature, u);
+        double pv[64];
+        for (int i = 0; i < A; ++i) pv[i] = from_prior ? root_prior[(size_t)g * A + i] : (double)v[i];
+        const int act = mzo_policy_action(A, pv, temperature, u);
         double* s = ar->state + (size_t)g * 4;
         mzs_cartpole st = {s[0], s[1], s[2], s[3]};
         const int terminated = mzs_cartpole_step(&st, act);

@@ -79,7 +79,7 @@ def fake_root(visits, priors, value_sum):
     return root
 
 
-def play(rs, A, L, limit, temperature, discount, unit_reward, seed_base):
+def play(rs, A, L, limit, temperature, discount, unit_reward, seed_base, from_prior=False):
     """One episode through the reference's Game; returns inputs + the Game."""
     obs0 = rs.standard_normal(4).astype(np.float32)
     obs = rs.standard_normal((L, 4)).astype(np.float32)
@@ -107,7 +107,15 @@ def play(rs, A, L, limit, temperature, discount, unit_reward, seed_base):
         roots[counter] = root.value()
         np.random.seed(seed_base + counter)
         us[counter] = np.random.RandomState(seed_base + counter).random_sample()
-        feedback = game.policy_step(policy=v.astype(np.float64), action=np.arange(A), temperature=temperature)
+        # MCTS.run hands policy_step the visit counts, or the priors when num_simulations == 0
+        # (monte_carlo_tree_search.py:218-221)
+        if from_prior:
+            v = np.zeros(A, np.int64)
+            visits[counter] = v
+            root = fake_root(v, p, np.float32(0))
+            roots[counter] = root.value()
+        feedback = game.policy_step(policy=np.asarray(p, np.float64) if from_prior else v.astype(np.float64),
+                                    action=np.arange(A), temperature=temperature)
         game.store_search_statistics(root)
         counter += 1
     n = counter
@@ -135,15 +143,19 @@ def main():
         (4, 33, 500, 2.0, 0.9, True), (2, 14, 500, 0.5, 0.8, False),
     ]
     games = []
-    for ci, (A, L, limit, temp, disc, unit) in enumerate(cfgs):
-        game, inp = play(rs, A, L, limit, temp, disc, unit, seed_base=1000 * (ci + 1))
+    cfgs += [(2, 15, 500, 0.0, 0.997, True, True), (3, 11, 500, 1.0, 0.997, True, True),
+             (2, 9, 500, 0.5, 0.997, True, True)]          # 7th field: policy = priors (0 simulations)
+    for ci, cfg in enumerate(cfgs):
+        A, L, limit, temp, disc, unit = cfg[:6]
+        from_prior = len(cfg) > 6
+        game, inp = play(rs, A, L, limit, temp, disc, unit, seed_base=1000 * (ci + 1), from_prior=from_prior)
         games.append(game)
         n = game.game_length
         assert n == min(L, limit)
         pre = f"g{ci}_"
         for k, v in inp.items():
             out[pre + k] = v
-        out[pre + "cfg"] = np.array([A, limit, temp, disc], np.float64)
+        out[pre + "cfg"] = np.array([A, limit, temp, disc, float(from_prior)], np.float64)
         out[pre + "actions"] = np.array([int(np.argmax(a)) for a in game.action_history], np.int32)
         out[pre + "child_visits"] = np.array(game.child_visits, np.float64)
         out[pre + "stored_root"] = np.array(game.root_values, np.float32)
@@ -159,8 +171,9 @@ def main():
 
     # ---- ReplayBuffer: priority / priority and priority / uniform sampling, window overflow,
     # update_value.  Unit-reward games with A == 2 and length >= 3 only (as CartPole gives).
-    pool = [g for g, c in zip(games, cfgs) if c[0] == 2 and g.game_length >= 3]
-    pool_ids = [i for i, (g, c) in enumerate(zip(games, cfgs)) if c[0] == 2 and g.game_length >= 3]
+    ok = lambda g, c: c[0] == 2 and g.game_length >= 3 and c[4] == 0.997 and len(c) == 6  # noqa: E731
+    pool = [g for g, c in zip(games, cfgs) if ok(g, c)]
+    pool_ids = [i for i, (g, c) in enumerate(zip(games, cfgs)) if ok(g, c)]
     out["rb_pool"] = np.array(pool_ids, np.int64)
     for ri, (pos_mode, window, td) in enumerate([("priority", 3, 3), ("uniform", 10, 10)]):
         rb = ReplayBuffer(window_size=window, batch_size=6, num_unroll=5, td_steps=td,

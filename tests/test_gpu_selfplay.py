@@ -64,7 +64,7 @@ def test_arena_step_vs_oracle(temperature):
     rs = np.random.RandomState(int(temperature * 100))
     for t in range(N * T):
         (v, rv, pr), res = fake_results(rs, G, 2, eng.device)
-        ar.step(temperature, res)
+        ar.step(temperature, res, num_simulations=50)
         n_alive = orc.step(v, rv, pr, temperature)
         torch.cuda.synchronize()
         assert int(ar.alive_count.item()) == n_alive
@@ -85,6 +85,37 @@ def test_arena_step_vs_oracle(temperature):
     ar.close(), eng.close()
 
 
+@pytest.mark.parametrize("temperature", [0.0, 1.0])
+def test_arena_step_zero_simulations(temperature):
+    """number_of_mcts_simulation = 0 (experiment_130..133 configs): policy_step gets the root priors
+    (monte_carlo_tree_search.py:218-221); through the real search kernel with S = 0."""
+    import torch
+    from muzero_amd.selfplay import Arena
+    from oracle import mz_oracle as mzo
+    G, T, N = 100, 30, 260
+    eng, dims, _ = make_engine(G, 0)
+    ar = Arena(eng, G, N, T)
+    orc = mzo.ArenaOracle(G, T, n_rows=N)
+    seeds = np.arange(N, dtype=np.int64) + 77
+    obs = ar.begin(0, seeds, 1)
+    orc.begin(seeds, 1)
+    for t in range(N * T):
+        eng.search(obs, None, None, 0, True)
+        r = {k: host(v) for k, v in eng.results_view().items()}
+        assert np.all(r["visits"] == 0)
+        ar.step(temperature)
+        n_alive = orc.step(r["visits"], r["root_value"], r["root_prior"], temperature, from_prior=True)
+        assert int(ar.alive_count.item()) == n_alive
+        if n_alive == 0:
+            break
+    got = arena_host(ar)
+    assert np.array_equal(got["length"], orc.length) and orc.length.min() >= 1
+    for k, w in (("obs", orc.traj_obs), ("action", orc.traj_action), ("root_value", orc.traj_root),
+                 ("policy", orc.traj_policy)):
+        assert np.array_equal(got[k], w), k
+    ar.close(), eng.close()
+
+
 @pytest.mark.parametrize("td,K", [(3, 5), (10, 5), (50, 10)])
 def test_make_batch_vs_oracle(td, K):
     import torch
@@ -98,7 +129,7 @@ def test_make_batch_vs_oracle(td, K):
         ar.begin(block * G, np.arange(G, dtype=np.int64) + 1000 * block, episode=block)
         for t in range(T):
             _, res = fake_results(rs, G, 2, eng.device)
-            ar.step(1.0, res)
+            ar.step(1.0, res, num_simulations=50)
         torch.cuda.synchronize()
         assert int(ar.alive_count.item()) == 0
     got = arena_host(ar)
@@ -183,3 +214,36 @@ def test_play_round_helper_and_learning_cycle():
     with pytest.raises(ValueError):
         SelfPlay(None, eng, tr, Arena(eng, G, 2 * N, T), store, S, N)   # too few rows for the window
     ar.close(), eng.close()
+
+
+def test_learning_cycle_from_reference_config(tmp_path):
+    """A reference-schema experiment config (the CartPole / mlp_model shape every shipped config has)
+    drives the batched cycle; td_steps 50 and unroll 10 as experiment_123."""
+    import json
+    from muzero_amd.config import load_config
+    from muzero_amd.selfplay import SelfPlay
+    cfg = {"game": {"env": "CartPole-v1", "render": None}, "random_seed": {"np_random_seed": 0, "torch_manual_seed": 0, "env_seed": 0},
+           "muzero": {"model_structure": "mlp_model", "state_space_dimensions": 31, "hidden_layer_dimensions": 64,
+                      "number_of_hidden_layer": 0, "k_hypothetical_steps": 10, "optimizer": "adam",
+                      "lr_scheduler": "cosineannealinglr", "learning_rate": 0.01, "loss_type": "general",
+                      "num_of_epoch": 10000, "device": "cpu", "load": False, "use_amp": False, "scaler_on": False,
+                      "bin_method": "uniform_bin", "bin_decomposition_number": 10},
+           "replaybuffer": {"window_size": 500, "batch_size": 128, "td_steps": 50, "game_sampling": "priority",
+                            "position_sampling": "priority"},
+           "monte_carlo_tree_search": {"pb_c_base": 19652, "pb_c_init": 1.25, "discount": 0.997,
+                                       "root_dirichlet_alpha": 0.25, "root_exploration_fraction": 0.25},
+           "gameplay": {"discount": 0.997, "limit_of_game_play": 500},
+           "learning_cycle": {"number_of_iteration": 10000, "number_of_self_play_before_training": 1,
+                              "number_of_training_before_self_play": 1, "number_of_mcts_simulation": 11,
+                              "tempererature_type": "linear_decrease_temperature", "model_tag_number": 123,
+                              "verbose": True, "number_of_worker_selfplay": 0},
+           "play_game_from_checkpoint": {}}
+    path = tmp_path / "experiment.json"
+    path.write_text(json.dumps(cfg))
+    np.random.seed(1)
+    loop = SelfPlay.from_config(load_config(str(path)), n_slots=256, games_per_iteration=600, window_size=1500)
+    assert loop.arena.G == 256 and loop.arena.T == 500 and loop.S == 11 and loop.store.td_steps == 50
+    rewards, losses = loop.run_config(number_of_iteration=3)
+    assert len(rewards) == 3 and all(np.isfinite(losses)) and len(loop.store) == 1501
+    assert loop.trainer.count == 3
+    loop.arena.close(), loop.eng.close()

@@ -35,7 +35,8 @@ def test_store_search_statistics(ci):
 def test_policy_step_action(ci):
     g = game(ci)
     temperature = float(g["cfg"][2])
-    got = [mzo.policy_action(v, temperature, u) for v, u in zip(g["visits"], g["u"])]
+    policy = g["priors"] if g["cfg"][4] else g["visits"]      # 0 simulations: MCTS.run returns the priors
+    got = [mzo.policy_action(v, temperature, u) for v, u in zip(policy, g["u"])]
     assert got == g["actions"].tolist()
 
 
