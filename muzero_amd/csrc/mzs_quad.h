@@ -162,10 +162,13 @@ __device__ __forceinline__ void quad_load_x(const float* row, int g, float (&x)[
     x[12] = v3.x, x[13] = v3.y, x[14] = v3.z, x[15] = v3.w;
 }
 
-template <int SD, int NA, int H>
+/* kMid: the tied mid layer of each net (neural_network_mlp_model.py:38-39, applied m.L times)
+ * is register resident too: H more weight rows per net */
+template <int SD, int NA, int H, bool kMid = false>
 struct QuadWeights {
     float d_in[SD], d_h[H], p_in[SD], p_h[H];
-    f32x4 b_d_in, b_d_h, b_p_in, b_p_h;
+    float d_mid[kMid ? H : 1], p_mid[kMid ? H : 1];
+    f32x4 b_d_in, b_d_h, b_p_in, b_p_h, b_d_mid, b_p_mid;
 };
 
 /* 16-byte tree node of this kernel: everything pUCT reads about a child in one ds_read_b128.
@@ -200,8 +203,8 @@ struct QuadLayout {
     int g_vsum, g_path, g_hid, g_leafs, g_bytes;        /* per game: nodes at 0         */
 };
 
-template <int SD, int NA, int H>
-__device__ __forceinline__ void quad_load_weights(const Model& m, QuadWeights<SD, NA, H>& W,
+template <int SD, int NA, int H, bool kMid>
+__device__ __forceinline__ void quad_load_weights(const Model& m, QuadWeights<SD, NA, H, kMid>& W,
                                                   const QuadLane& q) {
     const float* __restrict__ w = m.w;
     const int n = quad_neuron_of_lane(q.lane);
@@ -221,6 +224,14 @@ __device__ __forceinline__ void quad_load_weights(const Model& m, QuadWeights<SD
     W.b_d_h = b4(m.d_heads.b_off);
     W.b_p_in = b4(m.p_in.b_off);
     W.b_p_h = b4(m.p_heads.b_off);
+    if constexpr (kMid) {
+#pragma unroll
+        for (int k = 0; k < H; ++k) W.d_mid[k] = w[m.d_mid.w_off + k * 64 + n];
+#pragma unroll
+        for (int k = 0; k < H; ++k) W.p_mid[k] = w[m.p_mid.w_off + k * 64 + n];
+        W.b_d_mid = b4(m.d_mid.b_off);
+        W.b_p_mid = b4(m.p_mid.b_off);
+    }
 }
 
 __device__ __forceinline__ f32x4 elu4(const f32x4 v) {
@@ -306,13 +317,19 @@ __device__ __forceinline__ f32x4 quad_scale_to_bound(const f32x4 o, const bool (
  * low half (block eb = 0 holds actions 0..3: lanes 0..3), value logits in the high half; the two
  * softmaxes run in the same instructions.  Returns the value's support expectation (before the
  * inverse transform) in the high half's lanes. */
-template <int SD, int NA, int H>
-__device__ __forceinline__ float quad_prediction(const QuadWeights<SD, NA, H>& W, const QuadLds& L,
-                                                 const QuadLane& q, const float* h, f32x4* prior) {
+template <int SD, int NA, int H, bool kMid>
+__device__ __forceinline__ float quad_prediction(const QuadWeights<SD, NA, H, kMid>& W, const QuadLds& L,
+                                                 const QuadLane& q, const float* h, f32x4* prior, int n_mid) {
     float x[16];
     quad_load_x(h, q.grp & 1, x);
     f32x4 acc = quad_dense<SD>(W.p_in, x, W.b_p_in);
     quad_trunk_to_x(L, q, acc, x);
+    if constexpr (kMid) {
+        for (int l = 0; l < n_mid; ++l) {
+            acc = quad_dense<H>(W.p_mid, x, W.b_p_mid);
+            quad_trunk_to_x(L, q, acc, x);
+        }
+    }
     acc = quad_dense<H>(W.p_h, x, W.b_p_h);
     const int i0 = 4 * q.eb, lim = q.half ? SD : NA;
     const bool valid[4] = {i0 < lim, i0 + 1 < lim, i0 + 2 < lim, i0 + 3 < lim};
@@ -325,9 +342,10 @@ __device__ __forceinline__ float quad_prediction(const QuadWeights<SD, NA, H>& W
 /* Dynamics_function on row `h` + action: reward logits in the low half, next-state
  * pre-activations in the high half; the new hidden state goes to row `hn` (LDS).  Returns the
  * reward's support expectation (before the inverse transform) in the low half's lanes. */
-template <int SD, int NA, int H>
-__device__ __forceinline__ float quad_dynamics(const QuadWeights<SD, NA, H>& W, const QuadLds& L,
-                                               const QuadLane& q, const float* h, int action, float* hn) {
+template <int SD, int NA, int H, bool kMid>
+__device__ __forceinline__ float quad_dynamics(const QuadWeights<SD, NA, H, kMid>& W, const QuadLds& L,
+                                               const QuadLane& q, const float* h, int action, float* hn,
+                                               int n_mid) {
     float x[16];
     quad_load_x(h, q.grp & 1, x);
     const float4 oh = *reinterpret_cast<const float4*>(L.onehot + action * 64 + q.n0);
@@ -335,6 +353,12 @@ __device__ __forceinline__ float quad_dynamics(const QuadWeights<SD, NA, H>& W, 
     /* one-hot action column (muzero_model.py:502): fma(1, w, acc) == acc + w */
     acc = f32x4{acc[0] + oh.x, acc[1] + oh.y, acc[2] + oh.z, acc[3] + oh.w};
     quad_trunk_to_x(L, q, acc, x);
+    if constexpr (kMid) {
+        for (int l = 0; l < n_mid; ++l) {
+            acc = quad_dense<H>(W.d_mid, x, W.b_d_mid);
+            quad_trunk_to_x(L, q, acc, x);
+        }
+    }
     acc = quad_dense<H>(W.d_h, x, W.b_d_h);
     const int i0 = 4 * q.eb;
     const bool valid[4] = {i0 < SD, i0 + 1 < SD, i0 + 2 < SD, i0 + 3 < SD};
@@ -372,6 +396,12 @@ __device__ __forceinline__ void quad_representation(const Model& m, const QuadLd
     float x[16];
     quad_trunk_to_x(L, q, acc, x);
     float wk[H];
+    for (int l = 0; l < m.L; ++l) { /* tied mid layer, streamed like the rest of this net */
+#pragma unroll
+        for (int k = 0; k < H; ++k) wk[k] = w[m.r_mid.w_off + k * 64 + n];
+        acc = quad_dense<H>(wk, x, b4(m.r_mid.b_off));
+        quad_trunk_to_x(L, q, acc, x);
+    }
 #pragma unroll
     for (int k = 0; k < H; ++k) wk[k] = w[m.r_out.w_off + k * 64 + n];
     acc = quad_dense<H>(wk, x, b4(m.r_out.b_off));

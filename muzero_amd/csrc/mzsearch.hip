@@ -259,7 +259,7 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 #define DIAG_ADD(i, a, b)
 #endif
 
-template <int SD, int NA, int H, bool kInjected>
+template <int SD, int NA, int H, bool kInjected, bool kMid = false>
 __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, const QuadLayout ql) {
     extern __shared__ __align__(16) unsigned char smem[];
     const QuadLane q = quad_lane();
@@ -277,11 +277,11 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
         inv64_s[i] = 1.0 / (double)(i > 0 ? i : 1); /* correctly rounded reciprocals (div_r*) */
         inv32_s[i] = 1.0f / (float)(i > 0 ? i : 1);
     }
-    QuadWeights<SD, NA, H> W;
+    QuadWeights<SD, NA, H, kMid> W;
     if (!kInjected) {
         for (int i = threadIdx.x; i < NA * 64; i += blockDim.x)
             onehot_s[i] = m.w[m.d_in.w_off + (SD + (i >> 6)) * 64 + (i & 63)];
-        quad_load_weights<SD, NA, H>(m, W, q);
+        quad_load_weights<SD, NA, H, kMid>(m, W, q);
     }
     __syncthreads();
 
@@ -338,7 +338,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
         for (int k = q.b; k < m.obs_dim; k += 16) L.trunk[q.c * 64 + k] = p.obs[(size_t)g * m.obs_dim + k];
         wave_sync();
         quad_representation<SD, NA, H>(m, L, q, L.hid);
-        (void)quad_prediction<SD, NA, H>(W, L, q, L.hid, &pr);   /* the root's value is not used */
+        (void)quad_prediction<SD, NA, H, kMid>(W, L, q, L.hid, &pr, m.L);   /* the root's value is not used */
     }
     if (q.b == 0) {
 #pragma unroll
@@ -380,10 +380,10 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
             /* dynamics on the parent's hidden state, prediction on the new one (mcts.py:180-192) */
             const int e_parent = (sel.pbase - 1) / NA;
             float* hn = L.hid + e_new * 32;
-            const float yr = quad_dynamics<SD, NA, H>(W, L, q, L.hid + e_parent * 32, sel.action, hn);
+            const float yr = quad_dynamics<SD, NA, H, kMid>(W, L, q, L.hid + e_parent * 32, sel.action, hn, m.L);
             DIAG_T(t2);
             DIAG_ADD(2, t1, t2);
-            const float yv = quad_prediction<SD, NA, H>(W, L, q, hn, &pr);
+            const float yv = quad_prediction<SD, NA, H, kMid>(W, L, q, hn, &pr, m.L);
             /* one inverse transform for both scalars: reward in the low half, value in the high */
             halves_pair(quad_inverse_value_transform(q.half ? yv : yr), reward, value);
         }
@@ -791,7 +791,14 @@ QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model) {
 /* the (S_dim, A, H) shapes the four-games-per-wave kernel is instantiated for */
 typedef void (*quad_kernel_t)(const SearchParams, const QuadLayout);
 quad_kernel_t pick_quad_kernel(const mzs_dims& d) {
-    if (d.n_mid_layers != 0 || d.obs_dim > 64) return nullptr;
+    if (d.obs_dim > 64) return nullptr;
+    if (d.n_mid_layers != 0) { /* tied mid layers (any count): H more register-resident rows per net */
+        if (d.state_dim == 31 && d.n_actions == 2 && d.hidden_dim == 64)
+            return k_search_quad<31, 2, 64, false, true>;
+        if (d.state_dim == 11 && d.n_actions == 2 && d.hidden_dim == 16)
+            return k_search_quad<11, 2, 16, false, true>;
+        return nullptr;
+    }
     if (d.state_dim == 31 && d.n_actions == 2 && d.hidden_dim == 64) return k_search_quad<31, 2, 64, false>;
     if (d.state_dim == 31 && d.n_actions == 4 && d.hidden_dim == 64) return k_search_quad<31, 4, 64, false>;
     if (d.state_dim == 11 && d.n_actions == 2 && d.hidden_dim == 16) return k_search_quad<11, 2, 16, false>;
