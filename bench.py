@@ -32,8 +32,21 @@ def algorithmic_bytes_per_sim(A, S_dim, dbar):
     return dbar * (24 * A + 8) + 8 * S_dim + 4 + 16 * A + 20 * (dbar + 1)
 
 
-def flops_per_sim(A, S_dim, H, L):
+def flops_per_sim(A, S_dim, H, L, kind=0):
+    if kind == 1:   # lstm_model: four heads, each Linear + L layers of three gate projections
+        def head(n_in, out):
+            return n_in * H + sum(3 * out * (H if l == 0 else out) for l in range(L))
+        return 2 * (2 * head(S_dim + A, S_dim) + head(S_dim, A) + head(S_dim, S_dim))
     return 2 * ((S_dim + A) * H + 2 * H * S_dim + S_dim * H + H * A + H * S_dim) + 2 * H * H * 2 * L
+
+
+def search_kernel_name(obs_dim, A, S_dim, H, L, kind):
+    """The kernel mzs_search dispatches to for these shapes (mzsearch.hip pick_quad_kernel)."""
+    shape = (S_dim, A, H)
+    quad = kind == 0 and obs_dim <= 64 and (shape in ((31, 2, 64), (31, 4, 64), (11, 2, 16)) if L == 0
+                                            else shape in ((31, 2, 64), (11, 2, 16)))
+    mid = "true" if L > 0 else "false"
+    return f"k_search_quad<{S_dim},{A},{H},false,{mid}>" if quad else "k_search_fused<false>"
 
 
 def cpu_baseline(dims, blob, S, pbc, seconds_target=12.0):
@@ -98,8 +111,11 @@ def main():
     dev = torch.device("cuda", local_rank)
 
     w = np.load(os.path.join(ROOT, "tests", "golden", f"weights_{args.weights}.npz"))
-    dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L"))
-    obs_dim, A, S_dim, H, L = dims
+    kind = int(w["kind"]) if "kind" in w.files else 0
+    dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (kind,)
+    obs_dim, A, S_dim, H, L = dims[:5]
+    kernel_name = search_kernel_name(obs_dim, A, S_dim, H, L, kind)
+    model_name = "LSTM" if kind == 1 else "MLP"
     G, S = args.games, args.sims
 
     # synthetic inputs of the BASELINE shape
@@ -154,17 +170,18 @@ def main():
         "value": value, "unit": "sims/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
-        "data": "synthetic (obs ~ U(-0.05,0.05)^4, tag-123 fixture weights, per-game "
+        "data": f"synthetic (obs ~ U(-0.05,0.05)^{obs_dim}, {args.weights} fixture weights, per-game "
                 "RandomState streams pre-drawn on host and resident in HBM)",
-        "config": {"workload": f"C2: CartPole-v1 MLP obs{obs_dim} A{A} S_dim{S_dim} H{H} L{L}, "
-                               f"{G} games/GPU x {S} sims, fused engine (1 launch per search, 4 games per wavefront)",
+        "config": {"workload": f"{'C2: CartPole-v1 ' if args.weights == 'tag123' else ''}{model_name} obs{obs_dim} A{A} "
+                               f"S_dim{S_dim} H{H} L{L}, {G} games/GPU x {S} sims, fused engine (1 launch per "
+                               f"search, {'4 games' if 'quad' in kernel_name else '1 game'} per wavefront)",
                    "games_per_gpu": G, "num_simulations": S, "engine": "fused",
                    "parallelism": f"games sharded over {world} GPU(s), no collective"},
     }
     if rank == 0:
         bps = algorithmic_bytes_per_sim(A, S_dim, dbar)
         ach = bps * G * S / (kernel_ms * 1e-3) / 1e9
-        fps = flops_per_sim(A, S_dim, H, L)
+        fps = flops_per_sim(A, S_dim, H, L, kind)
         fl = fps * G * S / (kernel_ms * 1e-3) / 1e12
         # The fused kernel holds both halves of the path: the tree work (HBM-roofline accounting,
         # SURVEY.md 8d bytes) and the MLP on v_mfma_f32_4x4x1 (MFMA-roofline accounting).  The
@@ -181,7 +198,7 @@ def main():
             pass
         out["roofline"] = {"bound": "mfma", "achieved": fl, "peak": F32_MATRIX_PEAK_TFLOPS,
                            "unit": "TFLOP/s", "frac": fl / F32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
-                           "kernel": "k_search_quad<31,2,64,false>", "kernel_ms": kernel_ms,
+                           "kernel": kernel_name, "kernel_ms": kernel_ms,
                            "flops_per_sim": fps, "mean_path_len": dbar,
                            "hbm_equiv": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": ach / HBM_PEAK_GBS, "bytes_per_sim": bps},

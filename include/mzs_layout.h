@@ -34,8 +34,14 @@ typedef struct mzs_dims {
     int32_t n_actions;    /* A                                               */
     int32_t state_dim;    /* S_dim: hidden-state width == support size       */
     int32_t hidden_dim;   /* H                                               */
-    int32_t n_mid_layers; /* L: how many times the tied mid layer is applied */
+    int32_t n_mid_layers; /* L: how many times the tied mid layer is applied (MLP);
+                             num_layers of every nn.LSTM (LSTM model, 1..MZS_LSTM_MAX_LAYERS) */
+    int32_t model_kind;   /* MZS_MODEL_MLP (0, 'mlp_model') or MZS_MODEL_LSTM ('lstm_model')    */
 } mzs_dims;
+
+#define MZS_MODEL_MLP 0
+#define MZS_MODEL_LSTM 1
+#define MZS_LSTM_MAX_LAYERS 4
 
 typedef struct mzs_blob_offsets {
     size_t r_in_w, r_in_b, r_mid_w, r_mid_b, r_out_w, r_out_b;
@@ -72,6 +78,64 @@ static inline mzs_blob_offsets mzs_blob_layout(const mzs_dims* d) {
     o.p_val_b = p; p += Sd;
     o.total = p;
     return o;
+}
+
+/* 'lstm_model' (neural_network_lstm_model.py:10-80), blob in state_dict order, torch layouts:
+ *   representation  state_norm.weight [Sd][obs], .bias [Sd]            (one Linear, :19-21)
+ *   dynamics        reward:               0.weight [H][Sd+A], 0.bias [H], then per LSTM layer l
+ *                     weight_ih_l [4*out][in_l], weight_hh_l [4*out][out], bias_ih_l, bias_hh_l [4*out]
+ *                     (out = Sd; in_0 = H, in_l = out; gate rows in torch order i, f, g, o)
+ *                   next_state_normalized: the same again (its own Linear, :33-47)
+ *   prediction      policy (out = A), value (out = Sd), each Linear [H][Sd] + LSTM (:63-77)
+ * Every call of the search feeds the LSTM a length-1 sequence with zero initial state, so
+ * weight_hh and the forget gate never contribute; they are carried in the blob for layout
+ * fidelity only. */
+typedef struct mzs_lstm_head_offsets {
+    size_t lin_w, lin_b;
+    size_t w_ih[MZS_LSTM_MAX_LAYERS], w_hh[MZS_LSTM_MAX_LAYERS];
+    size_t b_ih[MZS_LSTM_MAX_LAYERS], b_hh[MZS_LSTM_MAX_LAYERS];
+    int32_t in_dim, out_dim;
+} mzs_lstm_head_offsets;
+
+typedef struct mzs_lstm_offsets {
+    size_t r_w, r_b;
+    mzs_lstm_head_offsets rew, st, pol, val;
+    size_t total;
+} mzs_lstm_offsets;
+
+static inline size_t mzs_lstm_head_layout(mzs_lstm_head_offsets* h, size_t p, int in_dim, int H, int out,
+                                          int n_layers) {
+    h->in_dim = in_dim;
+    h->out_dim = out;
+    h->lin_w = p; p += (size_t)H * (size_t)in_dim;
+    h->lin_b = p; p += (size_t)H;
+    for (int l = 0; l < n_layers && l < MZS_LSTM_MAX_LAYERS; ++l) {
+        const size_t in_l = l == 0 ? (size_t)H : (size_t)out;
+        h->w_ih[l] = p; p += 4 * (size_t)out * in_l;
+        h->w_hh[l] = p; p += 4 * (size_t)out * (size_t)out;
+        h->b_ih[l] = p; p += 4 * (size_t)out;
+        h->b_hh[l] = p; p += 4 * (size_t)out;
+    }
+    return p;
+}
+
+static inline mzs_lstm_offsets mzs_lstm_layout(const mzs_dims* d) {
+    mzs_lstm_offsets o;
+    const int H = d->hidden_dim, Sd = d->state_dim, A = d->n_actions, L = d->n_mid_layers;
+    size_t p = 0;
+    o.r_w = p; p += (size_t)Sd * (size_t)d->obs_dim;
+    o.r_b = p; p += (size_t)Sd;
+    p = mzs_lstm_head_layout(&o.rew, p, Sd + A, H, Sd, L);
+    p = mzs_lstm_head_layout(&o.st, p, Sd + A, H, Sd, L);
+    p = mzs_lstm_head_layout(&o.pol, p, Sd, H, A, L);
+    p = mzs_lstm_head_layout(&o.val, p, Sd, H, Sd, L);
+    o.total = p;
+    return o;
+}
+
+/* floats in the weight blob of either model kind */
+static inline size_t mzs_blob_total(const mzs_dims* d) {
+    return d->model_kind == MZS_MODEL_LSTM ? mzs_lstm_layout(d).total : mzs_blob_layout(d).total;
 }
 
 static inline int32_t mzs_nodes_per_game(int32_t n_actions, int32_t num_simulations) {

@@ -22,6 +22,8 @@
  *   exp      : mzs_expf below (argument clamped to [-87, 88], Cody-Waite reduction + degree-6
  *              Cephes polynomial)
  *   expm1    : mzs_expm1f_neg below, x <= 0 only (ELU negative branch)
+ *   sigmoid  : 1 / (1 + exp(-x));  tanh: -t / (t + 2) with t = expm1(-2|x|), sign restored
+ *              (no cancellation for small |x|: the LSTM heads see pre-activations ~1e-2)
  *   sqrt, /  : correctly rounded (hipcc: -fhip-fp32-correctly-rounded-divide-sqrt)
  *
  * Reference formulas restated here:
@@ -106,6 +108,23 @@ MZS_FN float mzs_expm1f_neg(float x) {
 MZS_FN float mzs_elu(float x) {
     float y = mzs_expm1f_neg(x);
     return x > 0.0f ? x : y;
+}
+
+/* torch.sigmoid / torch.tanh of the LSTM cell (neural_network_lstm_model.py:35,41,65,71) */
+MZS_FN float mzs_sigmoid(float x) { return 1.0f / (1.0f + mzs_expf(-x)); }
+
+MZS_FN float mzs_tanh(float x) {
+    float a = __builtin_fabsf(x);
+    float t = mzs_expm1f_neg(-2.0f * a);
+    float y = -t / (t + 2.0f);
+    return x < 0.0f ? -y : y;
+}
+
+/* one nn.LSTM cell step from zero state (h0 = c0 = 0): c = sigmoid(i) * tanh(g) (the forget
+ * gate multiplies c0 = 0), h = sigmoid(o) * tanh(c) */
+MZS_FN float mzs_lstm_cell0(float gi, float gg, float go) {
+    float c = mzs_sigmoid(gi) * mzs_tanh(gg);
+    return mzs_sigmoid(go) * mzs_tanh(c);
 }
 
 /* Scalar tail of inverse_transform_with_support (muzero_model.py:585-586). */

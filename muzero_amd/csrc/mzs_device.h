@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "../../include/mzs_layout.h"
 #include "../../include/mzs_numeric.h"
 
 namespace mzs {
@@ -35,11 +36,25 @@ struct Layer {
     int n_pad;  /* padded fan-out, multiple of 64                    */
 };
 
+/* One head of the 'lstm_model' (neural_network_lstm_model.py:33-47, :63-77): Linear, then an
+ * L-layer nn.LSTM stepped once from zero state.  gate[l] is the fused (i | g | o) projection of
+ * layer l, each gate padded to out_pad columns, bias = bias_ih; bhh_off[l] = bias_hh in the same
+ * column order (added after the chain, as torch adds the two Linear results). */
+constexpr int kLstmMaxLayers = MZS_LSTM_MAX_LAYERS;
+struct LstmHead {
+    Layer lin;
+    Layer gate[kLstmMaxLayers];
+    int bhh_off[kLstmMaxLayers];
+    int n_out, out_pad;
+};
+
 struct Model {
     int obs_dim, A, Sd, H, L;
+    int kind;       /* MZS_MODEL_MLP / MZS_MODEL_LSTM (include/mzs_layout.h)                 */
     int seg_state;  /* offset of the next-state segment in the dynamics heads (reward at 0) */
     int seg_value;  /* offset of the value segment in the prediction heads (policy at 0)     */
     Layer r_in, r_mid, r_out, d_in, d_mid, d_heads, p_in, p_mid, p_heads;
+    LstmHead l_rew, l_st, l_pol, l_val; /* LSTM model only (r_in = its representation Linear) */
     const float* w; /* device weight store */
 };
 
@@ -264,9 +279,48 @@ __device__ __forceinline__ void seg_scale_to_bound(const float* seg, int n, floa
     wave_sync();
 }
 
+/* One LSTM head on the row x (LDS): h of the last layer, n_out values, in the returned LDS
+ * buffer (L.xa or L.xb).  Lane j owns unit j (and j + 64): the three gate chains of a unit are
+ * three columns of one fused dense layer, then the cell step is lane-local. */
+__device__ __forceinline__ float* lstm_head(const Model& m, const LstmHead& hd, const WaveLds& L,
+                                            const float* x, int extra_row, int lane) {
+    wave_dense<false>(m.w, hd.lin, x, L.xa, extra_row, lane);
+    float *cur = L.xa, *nxt = L.xb;
+    for (int l = 0; l < m.L; ++l) {
+        wave_dense<false>(m.w, hd.gate[l], cur, L.ob, -1, lane);
+        const float* bh = m.w + hd.bhh_off[l];
+        for (int j = lane; j < hd.n_out; j += kWave) {
+            const float gi = L.ob[j] + bh[j];
+            const float gg = L.ob[hd.out_pad + j] + bh[hd.out_pad + j];
+            const float go = L.ob[2 * hd.out_pad + j] + bh[2 * hd.out_pad + j];
+            nxt[j] = mzs_lstm_cell0(gi, gg, go);
+        }
+        wave_sync();
+        float* t = cur;
+        cur = nxt;
+        nxt = t;
+    }
+    return cur;
+}
+
+/* copy n values LDS -> LDS (and global if not null) */
+__device__ __forceinline__ void seg_copy(const float* src, int n, float* dst, float* gdst, int lane) {
+    for (int j = lane; j < n; j += kWave) {
+        const float v = src[j];
+        dst[j] = v;
+        if (gdst) gdst[j] = v;
+    }
+    wave_sync();
+}
+
 /* Representation_function.forward: input in L.xh[0..obs), hidden state to L.xh and gdst */
 __device__ __forceinline__ void model_representation(const Model& m, const WaveLds& L,
                                                      float* gdst, int lane) {
+    if (m.kind == MZS_MODEL_LSTM) { /* one Linear (neural_network_lstm_model.py:19-21) */
+        wave_dense<false>(m.w, m.r_in, L.xh, L.ob, -1, lane);
+        seg_copy(L.ob, m.Sd, L.xh, gdst, lane);
+        return;
+    }
     wave_dense<true>(m.w, m.r_in, L.xh, L.xa, -1, lane);
     float* t = wave_mid_layers(m, m.r_mid, L.xa, L.xb, lane);
     wave_dense<false>(m.w, m.r_out, t, L.ob, -1, lane);
@@ -277,6 +331,14 @@ __device__ __forceinline__ void model_representation(const Model& m, const WaveL
  * state to L.xh and gdst */
 __device__ __forceinline__ float model_dynamics(const Model& m, const WaveLds& L, int action,
                                                 float* gdst, int lane) {
+    if (m.kind == MZS_MODEL_LSTM) {
+        const float* r = lstm_head(m, m.l_rew, L, L.xh, m.Sd + action, lane);
+        const float reward = seg_support_scalar(r, m.Sd, lane);
+        wave_sync();
+        const float* s = lstm_head(m, m.l_st, L, L.xh, m.Sd + action, lane);
+        seg_copy(s, m.Sd, L.xh, gdst, lane);
+        return reward;
+    }
     wave_dense<true>(m.w, m.d_in, L.xh, L.xa, m.Sd + action, lane);
     float* t = wave_mid_layers(m, m.d_mid, L.xa, L.xb, lane);
     wave_dense<false>(m.w, m.d_heads, t, L.ob, -1, lane);
@@ -288,6 +350,13 @@ __device__ __forceinline__ float model_dynamics(const Model& m, const WaveLds& L
 /* Prediction_function.forward on L.xh: softmax policy as lane pairs, value (uniform) */
 __device__ __forceinline__ float model_prediction(const Model& m, const WaveLds& L, Pair* policy,
                                                   int lane) {
+    if (m.kind == MZS_MODEL_LSTM) {
+        const float* pl = lstm_head(m, m.l_pol, L, L.xh, -1, lane);
+        *policy = seg_softmax(seg_load(pl, m.A, lane));
+        wave_sync();
+        const float* vl = lstm_head(m, m.l_val, L, L.xh, -1, lane);
+        return seg_support_scalar(vl, m.Sd, lane);
+    }
     wave_dense<true>(m.w, m.p_in, L.xh, L.xa, -1, lane);
     float* t = wave_mid_layers(m, m.p_mid, L.xa, L.xb, lane);
     wave_dense<false>(m.w, m.p_heads, t, L.ob, -1, lane);

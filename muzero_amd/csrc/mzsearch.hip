@@ -700,6 +700,39 @@ struct StoreBuilder {
     }
 };
 
+/* 'lstm_model' head: Linear(in_dim -> H) + per layer the fused (i | g | o) gate projection */
+LstmHead describe_lstm_head(StoreBuilder* sb, int lin_rows, int lin_k, int H, int n_out, int n_layers) {
+    LstmHead hd;
+    hd.n_out = n_out;
+    hd.out_pad = round_up(n_out, 64);
+    hd.lin = sb->add(lin_rows, lin_k, round_up(H, 64));
+    for (int l = 0; l < kLstmMaxLayers; ++l) {
+        hd.gate[l] = Layer{0, 0, 0, 0};
+        hd.bhh_off[l] = 0;
+        if (l >= n_layers) continue;
+        const int in_l = l == 0 ? H : n_out;
+        hd.gate[l] = sb->add(in_l, in_l, 3 * hd.out_pad);
+        hd.bhh_off[l] = (int)sb->data.size();
+        sb->data.resize(sb->data.size() + (size_t)3 * hd.out_pad, 0.0f);
+    }
+    return hd;
+}
+
+void fill_lstm_head(StoreBuilder* sb, const LstmHead& hd, const float* B, const mzs_lstm_head_offsets& o, int H,
+                    int n_layers) {
+    const int n = hd.n_out;
+    sb->fill(hd.lin, B + o.lin_w, B + o.lin_b, H, o.in_dim, o.in_dim, 0);
+    for (int l = 0; l < n_layers; ++l) {
+        const int in_l = l == 0 ? H : n;
+        const int gate_row[3] = {0, 2, 3}; /* torch rows i, f, g, o: f never contributes (c0 = 0) */
+        for (int q = 0; q < 3; ++q) {
+            const size_t r0 = (size_t)gate_row[q] * n;
+            sb->fill(hd.gate[l], B + o.w_ih[l] + r0 * in_l, B + o.b_ih[l] + r0, n, in_l, in_l, q * hd.out_pad);
+            for (int j = 0; j < n; ++j) sb->data[(size_t)hd.bhh_off[l] + q * hd.out_pad + j] = B[o.b_hh[l] + r0 + j];
+        }
+    }
+}
+
 void describe_model(const mzs_dims& d, Model* m, StoreBuilder* sb) {
     const int H = d.hidden_dim, Sd = d.state_dim, A = d.n_actions, HP = round_up(H, 64);
     m->obs_dim = d.obs_dim;
@@ -707,8 +740,19 @@ void describe_model(const mzs_dims& d, Model* m, StoreBuilder* sb) {
     m->Sd = Sd;
     m->H = H;
     m->L = d.n_mid_layers;
+    m->kind = d.model_kind;
     m->seg_state = round_up(Sd, 32);
     m->seg_value = round_up(A, 32);
+    if (d.model_kind == MZS_MODEL_LSTM) {
+        const Layer none{0, 0, 0, 0};
+        m->r_mid = m->r_out = m->d_in = m->d_mid = m->d_heads = m->p_in = m->p_mid = m->p_heads = none;
+        m->r_in = sb->add(d.obs_dim, d.obs_dim, round_up(Sd, 64));
+        m->l_rew = describe_lstm_head(sb, Sd + A, Sd, H, Sd, d.n_mid_layers);
+        m->l_st = describe_lstm_head(sb, Sd + A, Sd, H, Sd, d.n_mid_layers);
+        m->l_pol = describe_lstm_head(sb, Sd, Sd, H, A, d.n_mid_layers);
+        m->l_val = describe_lstm_head(sb, Sd, Sd, H, Sd, d.n_mid_layers);
+        return;
+    }
     m->r_in = sb->add(d.obs_dim, d.obs_dim, HP);
     m->r_mid = sb->add(H, H, HP);
     m->r_out = sb->add(H, H, round_up(Sd, 64));
@@ -729,14 +773,20 @@ LdsLayout make_lds_layout(const Model& m, int n_nodes, int S) {
     off += round_up((S + 2) * 2, 16);
     l.off_xh = off;
     off += round_up((m.obs_dim > m.Sd ? m.obs_dim : m.Sd) * 4, 16);
-    l.off_xa = off;
-    off += round_up(m.H, 64) * 4;
-    l.off_xb = off;
-    off += round_up(m.H, 64) * 4;
-    l.off_ob = off;
+    int act = round_up(m.H, 64); /* trunk activations; the LSTM heads also keep h (<= out_pad) there */
     int ob = m.r_out.n_pad;
     ob = m.d_heads.n_pad > ob ? m.d_heads.n_pad : ob;
     ob = m.p_heads.n_pad > ob ? m.p_heads.n_pad : ob;
+    if (m.kind == MZS_MODEL_LSTM) {
+        const int out_pad = round_up(m.Sd > m.A ? m.Sd : m.A, 64);
+        act = act > out_pad ? act : out_pad;
+        ob = 3 * out_pad;
+    }
+    l.off_xa = off;
+    off += act * 4;
+    l.off_xb = off;
+    off += act * 4;
+    l.off_ob = off;
     off += ob * 4;
     l.bytes = round_up(off, 16);
     return l;
@@ -791,7 +841,7 @@ QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model) {
 /* the (S_dim, A, H) shapes the four-games-per-wave kernel is instantiated for */
 typedef void (*quad_kernel_t)(const SearchParams, const QuadLayout);
 quad_kernel_t pick_quad_kernel(const mzs_dims& d) {
-    if (d.obs_dim > 64) return nullptr;
+    if (d.obs_dim > 64 || d.model_kind != MZS_MODEL_MLP) return nullptr;
     if (d.n_mid_layers != 0) { /* tied mid layers (any count): H more register-resident rows per net */
         if (d.state_dim == 31 && d.n_actions == 2 && d.hidden_dim == 64)
             return k_search_quad<31, 2, 64, false, true>;
@@ -884,7 +934,7 @@ const char* mzs_version(void) { return "mzsearch 0.1 (gfx950)"; }
 
 size_t mzs_weight_count(const mzs_dims* dims) {
     if (!dims) return 0;
-    return mzs_blob_layout(dims).total;
+    return mzs_blob_total(dims);
 }
 
 int mzs_create(const mzs_config* cfg, mzs_handle** out) {
@@ -893,6 +943,10 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     if (d.obs_dim < 1 || d.n_actions < 1 || d.state_dim < 1 || d.hidden_dim < 1 ||
         d.n_mid_layers < 0)
         return fail(MZS_E_ARG, "dims must be positive");
+    if (d.model_kind != MZS_MODEL_MLP && d.model_kind != MZS_MODEL_LSTM)
+        return fail(MZS_E_ARG, "model_kind must be MZS_MODEL_MLP or MZS_MODEL_LSTM");
+    if (d.model_kind == MZS_MODEL_LSTM && (d.n_mid_layers < 1 || d.n_mid_layers > MZS_LSTM_MAX_LAYERS))
+        return fail(MZS_E_ARG, "lstm_model: 1..4 LSTM layers (n_mid_layers)");
     if (d.n_actions > 64) return fail(MZS_E_ARG, "n_actions > 64 not supported (one lane per child)");
     if (d.state_dim > 128) return fail(MZS_E_ARG, "state_dim > 128 not supported (two logits per lane)");
     if (cfg->max_games < 1 || cfg->max_simulations < 0) return fail(MZS_E_ARG, "bad sizes");
@@ -927,7 +981,7 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     h->tree.max_sims = cfg->max_simulations;
     int rc = MZS_OK;
     const size_t ts = (size_t)h->tree.stride;
-    const size_t n_blob = mzs_blob_layout(&d).total;
+    const size_t n_blob = mzs_blob_total(&d);
     if ((rc = dev_alloc(h, &h->w_dev, h->w_floats)) ||
         (rc = dev_alloc(h, &h->blob_dev, n_blob)) ||
         (rc = dev_alloc(h, &h->store_index_dev, n_blob)) ||
@@ -973,9 +1027,9 @@ int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats) {
     if (!h || !blob) return fail(MZS_E_ARG, "null argument");
     const mzs_dims& d = h->cfg.dims;
     const mzs_blob_offsets o = mzs_blob_layout(&d);
-    if (n_floats != o.total) {
+    if (n_floats != mzs_blob_total(&d)) {
         char msg[128];
-        std::snprintf(msg, sizeof msg, "weight blob has %zu floats, expected %zu", n_floats, o.total);
+        std::snprintf(msg, sizeof msg, "weight blob has %zu floats, expected %zu", n_floats, mzs_blob_total(&d));
         return fail(MZS_E_ARG, msg);
     }
     HIP_TRY(hipSetDevice(h->cfg.device));
@@ -986,6 +1040,18 @@ int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats) {
     StoreBuilder sb;
     Model m;
     describe_model(d, &m, &sb);
+    if (d.model_kind == MZS_MODEL_LSTM) {
+        const mzs_lstm_offsets lo = mzs_lstm_layout(&d);
+        sb.fill(m.r_in, B + lo.r_w, B + lo.r_b, Sd, ob, ob, 0);
+        fill_lstm_head(&sb, m.l_rew, B, lo.rew, H, d.n_mid_layers);
+        fill_lstm_head(&sb, m.l_st, B, lo.st, H, d.n_mid_layers);
+        fill_lstm_head(&sb, m.l_pol, B, lo.pol, H, d.n_mid_layers);
+        fill_lstm_head(&sb, m.l_val, B, lo.val, H, d.n_mid_layers);
+        HIP_TRY(hipMemcpy(h->blob_dev, B, n_floats * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->w_dev, sb.data.data(), sb.data.size() * sizeof(float), hipMemcpyHostToDevice));
+        h->have_weights = true;
+        return MZS_OK;
+    }
     sb.index.assign(n_floats, 0);
     sb.fill_at(m.r_in, B, o.r_in_w, o.r_in_b, H, ob, ob, 0);
     sb.fill_at(m.r_out, B, o.r_out_w, o.r_out_b, Sd, H, H, 0);
@@ -1232,6 +1298,9 @@ int mzs_train_create(mzs_handle* h, int32_t max_batch, int32_t unroll_steps) {
     if (!h) return fail(MZS_E_ARG, "null handle");
     if (max_batch < 1 || unroll_steps < 1) return fail(MZS_E_ARG, "bad batch or unroll length");
     const mzs_dims& d = h->cfg.dims;
+    if (d.model_kind != MZS_MODEL_MLP)
+        return fail(MZS_E_ARG, "training kernels exist for mlp_model only (the reference feeds its LSTM the "
+                               "training batch as one sequence, neural_network_lstm_model.py:35: not built)");
     if (d.state_dim > 64 || d.n_actions > 64)
         return fail(MZS_E_ARG, "training kernels hold one logit per lane: state_dim and n_actions <= 64");
     if (h->tape_dev) return fail(MZS_E_STATE, "mzs_train_create was already called on this handle");
@@ -1335,7 +1404,7 @@ int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, dou
 int mzs_get_weights(mzs_handle* h, float* blob_out, size_t n_floats) {
     if (!h || !blob_out) return fail(MZS_E_ARG, "null argument");
     if (!h->have_weights) return fail(MZS_E_STATE, "mzs_set_weights has not been called");
-    if (n_floats != mzs_blob_layout(&h->cfg.dims).total) return fail(MZS_E_ARG, "wrong blob size");
+    if (n_floats != mzs_blob_total(&h->cfg.dims)) return fail(MZS_E_ARG, "wrong blob size");
     HIP_TRY(hipSetDevice(h->cfg.device));
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(blob_out, h->blob_dev, n_floats * sizeof(float), hipMemcpyDefault));

@@ -65,8 +65,24 @@ def _action_dictionary(space, bin_method, bins):
     return parts[0]
 
 
-def blob_layout(obs_dim, A, S_dim, H, L):
+def lstm_blob_layout(obs_dim, A, S_dim, H, L):
+    """'lstm_model' blob (include/mzs_layout.h mzs_lstm_layout): the state_dict order of
+    neural_network_lstm_model.py's three modules."""
+    def head(p, in_dim, out):
+        t = [(f"{p}_lin_w", (H, in_dim)), (f"{p}_lin_b", (H,))]
+        for l in range(L):
+            in_l = H if l == 0 else out
+            t += [(f"{p}_w_ih_l{l}", (4 * out, in_l)), (f"{p}_w_hh_l{l}", (4 * out, out)),
+                  (f"{p}_b_ih_l{l}", (4 * out,)), (f"{p}_b_hh_l{l}", (4 * out,))]
+        return t
+    return ([("r_w", (S_dim, obs_dim)), ("r_b", (S_dim,))] + head("d_rew", S_dim + A, S_dim) +
+            head("d_st", S_dim + A, S_dim) + head("p_pol", S_dim, A) + head("p_val", S_dim, S_dim))
+
+
+def blob_layout(obs_dim, A, S_dim, H, L, kind=0):
     """(name, shape) of every tensor in the packed blob, in order (include/mzs_layout.h)."""
+    if kind == _lib.MODEL_LSTM:
+        return lstm_blob_layout(obs_dim, A, S_dim, H, L)
     mid = lambda p: [(f"{p}_mid_w", (H, H)), (f"{p}_mid_b", (H,))] if L > 0 else []  # noqa: E731
     return ([("r_in_w", (H, obs_dim)), ("r_in_b", (H,))] + mid("r") +
             [("r_out_w", (S_dim, H)), ("r_out_b", (S_dim,))] +
@@ -117,9 +133,11 @@ class Muzero:
               device="cuda", num_of_epoch=300, hidden_layer_dimensions=64,
               number_of_hidden_layer=1, load=False, type_format=torch.float32, use_amp=False,
               scaler_on=False, bin_method="uniform_bin", bin_decomposition_number=10):
-        if model_structure not in (None, "mlp_model"):
-            raise NotImplementedError(f"model_structure={model_structure!r}: only 'mlp_model' has "
-                                      "MI355X kernels (SURVEY.md §8f lists the others as next)")
+        if model_structure not in (None, "mlp_model", "lstm_model"):
+            raise NotImplementedError(f"model_structure={model_structure!r}: 'mlp_model' and 'lstm_model' "
+                                      "have MI355X kernels (SURVEY.md §8f lists the others as next)")
+        if model_structure == "lstm_model" and not 1 <= int(number_of_hidden_layer) <= 4:
+            raise ValueError("lstm_model: number_of_hidden_layer is nn.LSTM's num_layers, 1..4 here")
         if type_format not in (torch.float32, None) or use_amp:
             raise NotImplementedError("the search path computes in fp32 (bit-exact contract)")
         self.model_structure = model_structure or "mlp_model"
@@ -152,11 +170,23 @@ class Muzero:
     def dims(self):
         return (int(self.observation_dimension), int(self.action_dimension),
                 int(self.state_dimension), int(self.hidden_layer_dimension),
-                int(self.number_of_hidden_layer))
+                int(self.number_of_hidden_layer),
+                _lib.MODEL_LSTM if self.model_structure == "lstm_model" else _lib.MODEL_MLP)
 
     def initiate_model_weight(self):
         """weights_init (neural_network_mlp_model.py:287-292): N(0, 1/137.035999) for every
         Linear weight and bias, drawn from torch's global generator."""
+        if self.model_structure == "lstm_model":
+            # weights_init touches nn.Linear only; nn.LSTM keeps torch's own U(-1/sqrt(out), 1/sqrt(out))
+            parts = []
+            for name, shape in blob_layout(*self.dims):
+                if "_lin_" in name or name in ("r_w", "r_b"):
+                    parts.append(torch.normal(0.0, 1 / 137.035999, size=shape).reshape(-1))
+                else:
+                    k = 1.0 / np.sqrt(shape[0] // 4)
+                    parts.append((torch.rand(shape) * 2 - 1).reshape(-1) * k)
+            self.set_weights(torch.cat(parts).numpy())
+            return
         n = sum(int(np.prod(s)) for _, s in blob_layout(*self.dims))
         self.set_weights(torch.normal(0.0, 1 / 137.035999, size=(n,)).numpy())
 
@@ -182,6 +212,10 @@ class Muzero:
         return out
 
     def load_reference_state_dicts(self, repr_sd, dyn_sd, pred_sd):
+        if self.model_structure == "lstm_model":     # blob order == state_dict order
+            g = lambda t: np.asarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, np.float32).ravel()  # noqa: E731
+            self.set_weights(np.concatenate([g(t) for sd in (repr_sd, dyn_sd, pred_sd) for t in sd.values()]))
+            return
         self.set_weights(blob_from_state_dicts(repr_sd, dyn_sd, pred_sd, self.number_of_hidden_layer))
 
     # ---------------------------------------------------------------- inference
@@ -229,6 +263,9 @@ class Muzero:
         [loss_nn, value_0, policy_0, value_1, policy_1, reward_1, ...] to store_loss.
         With torch.distributed initialised each rank passes its shard of the batch."""
         from . import train as tr
+        if self.model_structure != "mlp_model":
+            raise NotImplementedError("train(): kernels exist for 'mlp_model' only (the reference feeds its "
+                                      "LSTM the whole batch as one sequence, neural_network_lstm_model.py:35)")
         if self.loss_type != "general":
             raise NotImplementedError(f"loss_type={self.loss_type!r}: only the 'general' cross-entropy "
                                       "losses every shipped config uses (muzero_model.py:350-361)")

@@ -86,7 +86,7 @@ static void mid_layers(const mzs_dims* d, const float* W, const float* b, float*
 }
 
 typedef struct scratch {
-    float *t, *t2, *q;
+    float *t, *t2, *q, *g; /* g: 3 gate pre-activation rows of the LSTM heads */
 } scratch;
 
 static scratch scratch_new(const mzs_dims* d) {
@@ -94,15 +94,48 @@ static scratch scratch_new(const mzs_dims* d) {
     int n = d->hidden_dim > d->state_dim ? d->hidden_dim : d->state_dim;
     n = n > d->n_actions ? n : d->n_actions;
     n = mzs_pow2_ceil(n) * 2;
-    s.t = (float*)malloc(sizeof(float) * (size_t)n * 3);
+    s.t = (float*)malloc(sizeof(float) * (size_t)n * 6);
     s.t2 = s.t + n;
     s.q = s.t2 + n;
+    s.g = s.q + n;
     return s;
+}
+
+/* ---- 'lstm_model' (neural_network_lstm_model.py): Linear, then an L-layer nn.LSTM stepped once
+ * from zero state (the search calls it with one row = a length-1 unbatched sequence), h of the
+ * last layer taken by extract_tensor (:5-8).  Gate pre-activation = (W_ih x + b_ih) + b_hh
+ * (W_hh h0 = 0); rows of W_ih in torch order i, f, g, o. */
+static void lstm_head(const mzs_dims* d, const float* blob, const mzs_lstm_head_offsets* h, const float* x,
+                      int x_len, int extra_col, float* out, scratch* s) {
+    const int H = d->hidden_dim, n = h->out_dim;
+    dense(blob + h->lin_w, blob + h->lin_b, x, H, x_len, h->in_dim, s->t);
+    if (extra_col >= 0) /* one-hot action column, as in dyn_one */
+        for (int j = 0; j < H; ++j) s->t[j] = s->t[j] + blob[h->lin_w + (size_t)j * h->in_dim + extra_col];
+    const float* cur = s->t;
+    int in_l = H;
+    for (int l = 0; l < d->n_mid_layers; ++l) {
+        const float* W = blob + h->w_ih[l];
+        const float *bi = blob + h->b_ih[l], *bh = blob + h->b_hh[l];
+        dense(W, bi, cur, n, in_l, in_l, s->g);                                        /* i */
+        dense(W + (size_t)2 * n * in_l, bi + 2 * n, cur, n, in_l, in_l, s->g + n);      /* g */
+        dense(W + (size_t)3 * n * in_l, bi + 3 * n, cur, n, in_l, in_l, s->g + 2 * n);  /* o */
+        for (int j = 0; j < n; ++j)
+            s->t2[j] = mzs_lstm_cell0(s->g[j] + bh[j], s->g[n + j] + bh[2 * n + j], s->g[2 * n + j] + bh[3 * n + j]);
+        memcpy(s->t, s->t2, sizeof(float) * (size_t)n);
+        cur = s->t;
+        in_l = n;
+    }
+    memcpy(out, cur, sizeof(float) * (size_t)n);
 }
 
 /* Representation_function.forward (neural_network_mlp_model.py:43-44) */
 static void repr_one(const mzs_dims* d, const float* blob, const mzs_blob_offsets* o,
                      const float* obs, float* hidden, scratch* s) {
+    if (d->model_kind == MZS_MODEL_LSTM) { /* one Linear, no activation, no rescaling (lstm:19-21) */
+        const mzs_lstm_offsets lo = mzs_lstm_layout(d);
+        dense(blob + lo.r_w, blob + lo.r_b, obs, d->state_dim, d->obs_dim, d->obs_dim, hidden);
+        return;
+    }
     dense(blob + o->r_in_w, blob + o->r_in_b, obs, d->hidden_dim, d->obs_dim, d->obs_dim, s->t);
     elu_inplace(s->t, d->hidden_dim);
     mid_layers(d, blob + o->r_mid_w, blob + o->r_mid_b, s->t, s->t2);
@@ -117,6 +150,14 @@ static void dyn_one(const mzs_dims* d, const float* blob, const mzs_blob_offsets
                     const float* hidden, int action, float* reward, float* next_hidden,
                     scratch* s) {
     int H = d->hidden_dim, Sd = d->state_dim, ld = Sd + d->n_actions;
+    if (d->model_kind == MZS_MODEL_LSTM) {
+        const mzs_lstm_offsets lo = mzs_lstm_layout(d);
+        lstm_head(d, blob, &lo.rew, hidden, Sd, Sd + action, s->q, s);
+        *reward = mzo_support_to_scalar(s->q, Sd);
+        lstm_head(d, blob, &lo.st, hidden, Sd, Sd + action, s->q, s);
+        memcpy(next_hidden, s->q, sizeof(float) * (size_t)Sd);
+        return;
+    }
     const float* W = blob + o->d_in_w;
     dense(W, blob + o->d_in_b, hidden, H, Sd, ld, s->t);
     /* one-hot column: fma(1, w, acc) == acc + w; the zero columns add nothing */
@@ -134,6 +175,14 @@ static void dyn_one(const mzs_dims* d, const float* blob, const mzs_blob_offsets
 static void pred_one(const mzs_dims* d, const float* blob, const mzs_blob_offsets* o,
                      const float* hidden, float* policy, float* value, scratch* s) {
     int H = d->hidden_dim, Sd = d->state_dim, A = d->n_actions;
+    if (d->model_kind == MZS_MODEL_LSTM) {
+        const mzs_lstm_offsets lo = mzs_lstm_layout(d);
+        lstm_head(d, blob, &lo.pol, hidden, Sd, -1, s->q, s);
+        softmax(s->q, A, policy, s->t2);
+        lstm_head(d, blob, &lo.val, hidden, Sd, -1, s->q, s);
+        *value = mzo_support_to_scalar(s->q, Sd);
+        return;
+    }
     dense(blob + o->p_in_w, blob + o->p_in_b, hidden, H, Sd, Sd, s->t);
     elu_inplace(s->t, H);
     mid_layers(d, blob + o->p_mid_w, blob + o->p_mid_b, s->t, s->t2);

@@ -15,7 +15,7 @@ _LIB = None
 
 class Dims(C.Structure):
     _fields_ = [("obs_dim", C.c_int32), ("n_actions", C.c_int32), ("state_dim", C.c_int32),
-                ("hidden_dim", C.c_int32), ("n_mid_layers", C.c_int32)]
+                ("hidden_dim", C.c_int32), ("n_mid_layers", C.c_int32), ("model_kind", C.c_int32)]
 
 
 class SearchCfg(C.Structure):
@@ -63,8 +63,9 @@ def lib():
     return _LIB
 
 
-def dims(obs_dim, A, S_dim, H, L):
-    return Dims(int(obs_dim), int(A), int(S_dim), int(H), int(L))
+def dims(obs_dim, A, S_dim, H, L, kind=0):
+    """kind: 0 = 'mlp_model', 1 = 'lstm_model' (include/mzs_layout.h)."""
+    return Dims(int(obs_dim), int(A), int(S_dim), int(H), int(L), int(kind))
 
 
 def _p(a):

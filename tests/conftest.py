@@ -22,7 +22,7 @@ def fixture_weights(tag):
     """(oracle dims, blob) of tests/golden/weights_<tag>.npz"""
     from oracle import mz_oracle as mzo
     w = load_golden(f"weights_{tag}.npz")
-    d = mzo.dims(w["obs_dim"], w["A"], w["S_dim"], w["H"], w["L"])
+    d = mzo.dims(w["obs_dim"], w["A"], w["S_dim"], w["H"], w["L"], w.get("kind", 0))
     return d, w["blob"]
 
 
@@ -48,5 +48,6 @@ SEARCH_FIXTURES = [
     ("search_tag127_S50.npz", "tag127"), ("search_tag133_S50.npz", "tag133"),
     ("search_tag137_S25.npz", "tag137"), ("search_synA4_S50.npz", "synA4"),
     ("search_synA3_S30.npz", "synA3"),
+    ("search_lstmA_S50.npz", "lstmA"), ("search_lstmB_S30.npz", "lstmB"),      # 'lstm_model'
 ]
-MODEL_TAGS = ["tag123", "tag127", "tag133", "tag137", "synA4", "synA3"]
+MODEL_TAGS = ["tag123", "tag127", "tag133", "tag137", "synA4", "synA3", "lstmA", "lstmB"]

@@ -13,7 +13,8 @@ pytestmark = pytest.mark.gpu
 def model_for(tag):
     from muzero_amd.model import Muzero
     d, blob = fixture_weights(tag)
-    mz = Muzero(observation_space_dimensions=d.obs_dim, action_space_dimensions=d.n_actions,
+    mz = Muzero(model_structure="lstm_model" if d.model_kind == 1 else "mlp_model",
+                observation_space_dimensions=d.obs_dim, action_space_dimensions=d.n_actions,
                 state_space_dimensions=d.state_dim, hidden_layer_dimensions=d.hidden_dim,
                 number_of_hidden_layer=d.n_mid_layers, k_hypothetical_steps=5)
     mz.set_weights(blob)
@@ -24,7 +25,8 @@ def model_for(tag):
                                          ("search_tag123_S50.npz", "tag123", 12),
                                          ("search_synA4_S50.npz", "synA4", 8),
                                          ("search_tag123_S50_notrain.npz", "tag123", 6),
-                                         ("search_tag123_S0.npz", "tag123", 4)])
+                                         ("search_tag123_S0.npz", "tag123", 4),
+                                         ("search_lstmA_S50.npz", "lstmA", 6)])
 def test_run_is_drop_in(fname, tag, n):
     """Monte_carlo_tree_search.run: reference signature, global np.random stream."""
     from muzero_amd.search import Monte_carlo_tree_search

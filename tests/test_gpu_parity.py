@@ -31,7 +31,7 @@ ENGINES = ["fused", "generic"]   # fused = k_search_quad where the shape has one
 def make_engine(d, G, S, gamma, frac=0.25, engine="fused"):
     from muzero_amd import _lib
     from muzero_amd.engine import SearchEngine
-    return SearchEngine((d.obs_dim, d.n_actions, d.state_dim, d.hidden_dim, d.n_mid_layers),
+    return SearchEngine((d.obs_dim, d.n_actions, d.state_dim, d.hidden_dim, d.n_mid_layers, d.model_kind),
                         max_games=G, max_simulations=S, discount=gamma,
                         root_exploration_fraction=frac,
                         engine=_lib.ENGINE_FUSED if engine == "fused" else _lib.ENGINE_FUSED_GENERIC)

@@ -48,7 +48,7 @@ def test_blob_layout_and_model_wrapper():
         assert sum(int(np.prod(s)) for _, s in blob_layout(*dims)) == blob.size
     mz = Muzero(observation_space_dimensions=4, action_space_dimensions=2, state_space_dimensions=31,
                 hidden_layer_dimensions=64, number_of_hidden_layer=0, k_hypothetical_steps=5)
-    assert mz.dims == (4, 2, 31, 64, 0)
+    assert mz.dims == (4, 2, 31, 64, 0, 0)
     assert mz.action_dictionnary == [0, 1] and mz.action_dimension == 2
     w = mz.weights_blob()
     assert w.size == 12734 and abs(w.std() - 1 / 137.035999) < 5e-4   # weights_init
@@ -61,6 +61,14 @@ def test_blob_layout_and_model_wrapper():
         mz.set_weights(np.zeros(10, np.float32))
     with pytest.raises(NotImplementedError):
         Muzero(model_structure="vision_model", observation_space_dimensions=4, action_space_dimensions=2)
+    lz = Muzero(model_structure="lstm_model", observation_space_dimensions=4, action_space_dimensions=2,
+                state_space_dimensions=31, hidden_layer_dimensions=64, number_of_hidden_layer=2)
+    assert lz.dims == (4, 2, 31, 64, 2, 1)
+    nw = lz.named_weights()
+    assert nw["d_rew_w_ih_l1"].shape == (124, 31) and nw["p_pol_w_hh_l0"].shape == (8, 2)
+    assert np.abs(nw["p_val_w_ih_l0"]).max() <= 1 / np.sqrt(31) and abs(nw["r_w"].std() - 1 / 137.035999) < 2e-3
+    with pytest.raises(NotImplementedError):
+        lz.train(None)
 
 
 def test_model_checkpoint_roundtrip(tmp_path):
@@ -96,3 +104,16 @@ def test_config_schema():
         c = config.load_config(path)
         assert c["mi355x"] == config.MI355X_DEFAULTS
         config.mcts_kwargs(c), config.muzero_kwargs(c, 4, 2)
+
+
+def test_lstm_blob_layout_matches_header_and_fixture():
+    """'lstm_model' blob: the Python layout, the C header's mzs_lstm_layout (through the oracle's
+    blob size check) and the reference's state_dict sizes (fixture) agree."""
+    from muzero_amd.model import blob_layout
+    for tag in ("lstmA", "lstmB"):
+        w = load_golden(f"weights_{tag}.npz")
+        dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (1,)
+        lay = blob_layout(*dims)
+        assert sum(int(np.prod(s)) for _, s in lay) == w["blob"].size
+        names = [n for n, _ in lay]
+        assert names[:4] == ["r_w", "r_b", "d_rew_lin_w", "d_rew_lin_b"] and names[4] == "d_rew_w_ih_l0"
