@@ -43,8 +43,7 @@ def flops_per_sim(A, S_dim, H, L, kind=0):
 def search_kernel_name(obs_dim, A, S_dim, H, L, kind):
     """The kernel mzs_search dispatches to for these shapes (mzsearch.hip pick_quad_kernel)."""
     shape = (S_dim, A, H)
-    quad = kind == 0 and obs_dim <= 64 and (shape in ((31, 2, 64), (31, 4, 64), (11, 2, 16)) if L == 0
-                                            else shape in ((31, 2, 64), (11, 2, 16)))
+    quad = kind == 0 and obs_dim <= 64 and shape in ((31, 2, 64), (31, 3, 64), (31, 4, 64), (11, 2, 16))
     mid = "true" if L > 0 else "false"
     return f"k_search_quad<{S_dim},{A},{H},false,{mid}>" if quad else "k_search_fused<false>"
 

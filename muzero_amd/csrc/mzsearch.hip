@@ -842,16 +842,17 @@ QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model) {
 typedef void (*quad_kernel_t)(const SearchParams, const QuadLayout);
 quad_kernel_t pick_quad_kernel(const mzs_dims& d) {
     if (d.obs_dim > 64 || d.model_kind != MZS_MODEL_MLP) return nullptr;
-    if (d.n_mid_layers != 0) { /* tied mid layers (any count): H more register-resident rows per net */
-        if (d.state_dim == 31 && d.n_actions == 2 && d.hidden_dim == 64)
-            return k_search_quad<31, 2, 64, false, true>;
-        if (d.state_dim == 11 && d.n_actions == 2 && d.hidden_dim == 16)
-            return k_search_quad<11, 2, 16, false, true>;
-        return nullptr;
+    const bool mid = d.n_mid_layers != 0; /* tied mid layers (any count): H more register-resident rows per net */
+    if (d.state_dim == 31 && d.hidden_dim == 64) {
+        switch (d.n_actions) {
+            case 2: return mid ? k_search_quad<31, 2, 64, false, true> : k_search_quad<31, 2, 64, false, false>;
+            case 3: return mid ? k_search_quad<31, 3, 64, false, true> : k_search_quad<31, 3, 64, false, false>;
+            case 4: return mid ? k_search_quad<31, 4, 64, false, true> : k_search_quad<31, 4, 64, false, false>;
+            default: return nullptr;
+        }
     }
-    if (d.state_dim == 31 && d.n_actions == 2 && d.hidden_dim == 64) return k_search_quad<31, 2, 64, false>;
-    if (d.state_dim == 31 && d.n_actions == 4 && d.hidden_dim == 64) return k_search_quad<31, 4, 64, false>;
-    if (d.state_dim == 11 && d.n_actions == 2 && d.hidden_dim == 16) return k_search_quad<11, 2, 16, false>;
+    if (d.state_dim == 11 && d.n_actions == 2 && d.hidden_dim == 16)
+        return mid ? k_search_quad<11, 2, 16, false, true> : k_search_quad<11, 2, 16, false, false>;
     return nullptr;
 }
 

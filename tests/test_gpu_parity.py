@@ -162,7 +162,8 @@ def assert_search_equals_oracle(out, tree, ref):
 
 
 @pytest.mark.parametrize("shape", [(8, 4, 31, 64, 0), (4, 2, 31, 64, 0), (4, 2, 11, 16, 0),
-                                   (4, 2, 31, 64, 4), (4, 2, 31, 64, 1), (4, 2, 11, 16, 1)])
+                                   (4, 2, 31, 64, 4), (4, 2, 31, 64, 1), (4, 2, 11, 16, 1),
+                                   (6, 3, 31, 64, 0), (6, 3, 31, 64, 2), (8, 4, 31, 64, 1)])
 @pytest.mark.parametrize("G,S", [(37, 50), (5, 7), (1, 50)])
 def test_quad_shapes_vs_oracle(shape, G, S):
     """Every shape k_search_quad is instantiated for (incl. the LunarLander-like A = 4 one, which no
