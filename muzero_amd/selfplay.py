@@ -373,13 +373,25 @@ def play_round(engine, arena, seeds, episode, num_simulations, temperature, row0
     return moves
 
 
+def game_seed_index(rank, games_per_rank):
+    """Global index of the games rank `rank` plays in one iteration (muzero_amd.shard.game_range)."""
+    from .shard import game_range
+    return game_range(rank, games_per_rank)
+
+
 class SelfPlay:
     """learning_cycle (self_play.py:144-281) with batched self-play: every iteration plays
     `games_per_iteration` (number_of_self_play_before_training) episodes on arena.G slots, saves
     them in the ReplayStore in game order and runs the training steps on the same GPU, same weights."""
 
     def __init__(self, muzero, engine, trainer, arena, store, num_simulations, games_per_iteration=None,
-                 seed=0):
+                 seed=0, rank=None):
+        """Data-parallel use (one process per GPU, torch.distributed initialised): every rank plays
+        its own `games_per_iteration` games (seeds offset by rank, no collective), keeps its own
+        replay store, and Trainer.step sums the gradients of the per-rank batches with one
+        all-reduce, so the replicas' weights stay identical."""
+        from .shard import rank_world
+        self.rank = rank_world()[0] if rank is None else int(rank)
         self.mz, self.eng, self.trainer, self.arena, self.store = muzero, engine, trainer, arena, store
         self.S = int(num_simulations)
         self.N = int(games_per_iteration) if games_per_iteration else arena.G
@@ -452,7 +464,7 @@ class SelfPlay:
         """One round of N games into the next block of rows; returns their total rewards."""
         a, N = self.arena, self.N
         row0 = self.block * N
-        seeds = (np.arange(N, dtype=np.int64) * 2654435761 + self.seed) & 0x7FFFFFFF
+        seeds = (game_seed_index(self.rank, N) * 2654435761 + self.seed) & 0x7FFFFFFF
         self.lockstep_moves = play_round(self.eng, a, seeds, self.episode, self.S, temperature, row0)
         lengths_d = a.arrays["length"][row0:row0 + N]
         lengths = lengths_d.cpu().numpy()

@@ -112,3 +112,59 @@ def test_data_parallel_training_step_two_ranks(tmp_path):
     assert np.abs(r0["grad"] - g).max() <= 1e-5 * np.abs(g).max()
     assert abs(r0["loss"][-1] - fx["s0_losses"][0]) <= 1e-5 * fx["s0_losses"][0]
     assert np.abs(r0["blob"] - fx["s0_blob"]).max() <= 2e-3 * 0.01 + 1e-6
+
+
+SELFPLAY_WORKER = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["MZ_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MZ_ROOT"], "tests"))
+from muzero_amd import shard, selfplay
+from oracle import mz_oracle as mzo
+import torch.distributed as dist
+rank, world = shard.init("gloo")
+N, G, T = 40, 16, 30
+seeds = (selfplay.game_seed_index(rank, N) * 2654435761 + 5) & 0x7FFFFFFF
+ar = mzo.ArenaOracle(G, T, n_rows=N)
+ar.begin(seeds, episode=0)
+while True:                      # a fixed stand-in "search": visit counts from the observation
+    v = np.stack([(ar.obs[:, 2] > 0) * 30 + 10, (ar.obs[:, 2] <= 0) * 30 + 10], 1).astype(np.int32)
+    if ar.step(v, ar.obs[:, 0], np.full((G, 2), 0.5), 0.0) == 0:
+        break
+store = selfplay.ReplayStore(2 * N, 8, 5, 3)
+prio = mzo.make_priority(ar.length, ar.traj_reward, ar.traj_root, 3, selfplay.discount_powers(0.997, 3))
+store.save_games(np.arange(N), ar.length, priorities=prio)
+lens = [torch.zeros(N, dtype=torch.int32) for _ in range(world)]
+dist.all_gather(lens, torch.from_numpy(ar.length.copy()))
+if rank == 0:
+    np.savez(os.environ["MZ_OUT"], lengths=torch.cat(lens).numpy(), big_n=store.big_n_of_importance_sampling_ratio)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_self_play_shards_by_game_seed(tmp_path):
+    """Data-parallel self-play: ranks play disjoint games (seed = global game index), no collective
+    in the play path; the union equals one process playing all games (a game's trajectory depends
+    on its seed only).  CPU oracle arena stands in for the GPU arena (same arithmetic, bit-exact)."""
+    from muzero_amd import selfplay
+    from oracle import mz_oracle as mzo
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "sp.npz")
+    script = tmp_path / "sp_worker.py"
+    script.write_text(SELFPLAY_WORKER)
+    env = dict(os.environ, MZ_ROOT=ROOT, MZ_OUT=out, OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
+    subprocess.run(cmd, env=env, check=True, timeout=300, capture_output=True)
+    got = np.load(out)
+    N, G, T = 80, 7, 30          # one process, all 80 games, a different slot count on purpose
+    seeds = (np.arange(N, dtype=np.int64) * 2654435761 + 5) & 0x7FFFFFFF
+    ar = mzo.ArenaOracle(G, T, n_rows=N)
+    ar.begin(seeds, episode=0)
+    while True:
+        v = np.stack([(ar.obs[:, 2] > 0) * 30 + 10, (ar.obs[:, 2] <= 0) * 30 + 10], 1).astype(np.int32)
+        if ar.step(v, ar.obs[:, 0], np.full((G, 2), 0.5), 0.0) == 0:
+            break
+    assert np.array_equal(got["lengths"], ar.length)
+    assert int(got["big_n"]) == int(ar.length[:40].sum())
