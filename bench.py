@@ -127,7 +127,6 @@ def main():
     noise_d = torch.as_tensor(noise).to(dev)
     pack_h = torch.empty(G * (A + 1), dtype=torch.int32).pin_memory()   # visits [G,A] | root values [G]
     visits_h = pack_h[: G * A].view(G, A)
-    value_h = pack_h[G * A:].view(torch.float32)
     pack_d = eng.results_packed_view()
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]

@@ -191,6 +191,34 @@ def test_quad_shapes_vs_oracle(shape, G, S):
     eng.close()
 
 
+@pytest.mark.parametrize("shape,S", [((4, 2, 31, 64, 0), 120), ((4, 2, 31, 64, 0), 230), ((8, 4, 31, 64, 1), 110),
+                                     ((4, 2, 31, 64, 0), 400)])
+def test_deep_searches_vs_oracle(shape, S):
+    """More simulations than the benchmark's 50: the per-game LDS footprint grows, so the quad kernel
+    runs with fewer waves per block (S = 120: 2, S = 230: 1) and beyond that the engine falls back to
+    the generic kernel (S = 400); every variant == oracle on every output bit."""
+    from muzero_amd import rng
+    from muzero_amd.model import blob_layout
+    from oracle import mz_oracle as mzo
+    d = mzo.dims(*shape)
+    G = 11
+    rs = np.random.RandomState(S + sum(shape))
+    n_w = sum(int(np.prod(shp)) for _, shp in blob_layout(*shape))
+    blob = (rs.standard_normal(n_w) * 0.3).astype(np.float32)
+    obs = rs.uniform(-1, 1, size=(G, shape[0])).astype(np.float32)
+    dirichlet, noise = rng.noise_streams(np.arange(G) + 5, shape[1], S, 0.25, True)
+    eng = make_engine(d, G, S, 0.997)
+    eng.set_weights(blob)
+    eng.search(obs, dirichlet, noise, S, True)
+    out, tree = eng.results_host(), eng.tree_host()
+    ref = mzo.search(d, blob, S, 0.997, 0.25, eng.pbc, obs=obs, dirichlet=dirichlet, noise=noise,
+                     train=True, want=FULL_WANT)
+    assert not tree["status"].any()
+    assert_search_equals_oracle(out, tree, ref)
+    assert out["visits"].sum(1).tolist() == [S] * G
+    eng.close()
+
+
 def test_full_size_4096_games_vs_oracle():
     """BASELINE config C2: 4096 games x 50 simulations, tag-123 weights, against the
     oracle on all games (bit-exact), plus size-independent invariants."""
