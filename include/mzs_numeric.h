@@ -25,6 +25,12 @@
  *   sigmoid  : 1 / (1 + exp(-x));  tanh: -t / (t + 2) with t = expm1(-2|x|), sign restored
  *              (no cancellation for small |x|: the LSTM heads see pre-activations ~1e-2)
  *   sqrt, /  : correctly rounded (hipcc: -fhip-fp32-correctly-rounded-divide-sqrt)
+ *   a / Z for all elements of a softmax or scale_to_bound row (one divisor, many dividends):
+ *              mzs_div_r2 below — r = RN(1 / Z) once (a correctly rounded division), then per
+ *              element the product a * r and two fma residual corrections.  On every fixture and
+ *              test input this equals the correctly rounded quotient (Markstein's theorem covers
+ *              all but divisors with an all-ones significand and subnormal quotients); it is part
+ *              of the contract as an operation sequence, so GPU and oracle agree there as well.
  *
  * Reference formulas restated here:
  *   ELU                            torch.nn.ELU, neural_network_mlp_model.py:26,68,109
@@ -108,6 +114,16 @@ MZS_FN float mzs_expm1f_neg(float x) {
 MZS_FN float mzs_elu(float x) {
     float y = mzs_expm1f_neg(x);
     return x > 0.0f ? x : y;
+}
+
+/* quotient a / d from r = RN(1 / d): q0 = RN(a r), then q <- fma(fma(-q, d, a), r, q) twice */
+MZS_FN float mzs_div_r1(float a, float d, float r) {
+    float q = a * r;
+    return mzs_fma(mzs_fma(-q, d, a), r, q);
+}
+MZS_FN float mzs_div_r2(float a, float d, float r) {
+    float q = mzs_div_r1(a, d, r);
+    return mzs_fma(mzs_fma(-q, d, a), r, q);
 }
 
 /* torch.sigmoid / torch.tanh of the LSTM cell (neural_network_lstm_model.py:35,41,65,71) */

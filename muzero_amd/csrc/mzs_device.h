@@ -241,8 +241,9 @@ __device__ __forceinline__ Pair seg_softmax(const Pair q) {
     e.a = q.va ? mzs_expf(q.a - m) : 0.0f;
     e.b = q.vb ? mzs_expf(q.b - m) : 0.0f;
     const float Z = wave_tree_sum(e.a + e.b);
-    e.a = e.a / Z;
-    e.b = e.b / Z;
+    const float rz = 1.0f / Z;   /* contract: one reciprocal, corrected products (mzs_div_r2) */
+    e.a = mzs_div_r2(e.a, Z, rz);
+    e.b = mzs_div_r2(e.b, Z, rz);
     return e;
 }
 
@@ -264,15 +265,15 @@ __device__ __forceinline__ void seg_scale_to_bound(const float* seg, int n, floa
     const float pinf = __builtin_inff();
     const float mn = wave_min(fminf(q.va ? q.a : pinf, q.vb ? q.b : pinf));
     const float mx = wave_max(fmaxf(q.va ? q.a : -pinf, q.vb ? q.b : -pinf));
-    const float sc = mzs_bound_scale(mn, mx);
+    const float sc = mzs_bound_scale(mn, mx), rs = 1.0f / sc;
     const int i = 2 * lane;
     if (q.va) {
-        const float y = (q.a - mn) / sc;
+        const float y = mzs_div_r2(q.a - mn, sc, rs);
         dst[i] = y;
         if (gdst) gdst[i] = y;
     }
     if (q.vb) {
-        const float y = (q.b - mn) / sc;
+        const float y = mzs_div_r2(q.b - mn, sc, rs);
         dst[i + 1] = y;
         if (gdst) gdst[i + 1] = y;
     }

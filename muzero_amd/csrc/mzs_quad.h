@@ -251,6 +251,18 @@ __device__ __forceinline__ void quad_trunk_to_x(const QuadLds& L, const QuadLane
     wave_sync();
 }
 
+/* a / d given r = RN(1/d): product, then fma residual corrections (Markstein).  Each step
+ * takes a faithful quotient to the correctly rounded one; one step is exhaustively verified for
+ * fp32 with integer d <= 512 (tests/test_division.py), elsewhere two steps are used.  No
+ * overflow / underflow on this path: operands are visit counts, values and priors. */
+__device__ __forceinline__ float div_r1(float a, float d, float r) { return mzs_div_r1(a, d, r); }
+__device__ __forceinline__ float div_r2(float a, float d, float r) { return mzs_div_r2(a, d, r); }
+__device__ __forceinline__ double div_r2(double a, double d, double r) {
+    double q = a * r;
+    q = __builtin_fma(__builtin_fma(-q, d, a), r, q);
+    return __builtin_fma(__builtin_fma(-q, d, a), r, q);
+}
+
 /* softmax over the valid logits of this lane's half (contract exp + sum) */
 __device__ __forceinline__ f32x4 quad_softmax(const f32x4 o, const bool (&valid)[4]) {
     const float ninf = -__builtin_inff();
@@ -263,8 +275,9 @@ __device__ __forceinline__ f32x4 quad_softmax(const f32x4 o, const bool (&valid)
         e[r] = valid[r] ? ex : 0.0f;
     }
     const float Z = half_sum(sum4(e));
+    const float rz = 1.0f / Z;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) e[r] = e[r] / Z;
+    for (int r = 0; r < 4; ++r) e[r] = div_r2(e[r], Z, rz);
     return e;
 }
 
@@ -306,10 +319,10 @@ __device__ __forceinline__ f32x4 quad_scale_to_bound(const f32x4 o, const bool (
                                          valid[2] ? o[2] : ninf, valid[3] ? o[3] : ninf}));
     const float mn = -half_max(max4(f32x4{valid[0] ? -o[0] : ninf, valid[1] ? -o[1] : ninf,
                                           valid[2] ? -o[2] : ninf, valid[3] ? -o[3] : ninf}));
-    const float sc = mzs_bound_scale(mn, mx);
+    const float sc = mzs_bound_scale(mn, mx), rs = 1.0f / sc;
     f32x4 y;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) y[r] = valid[r] ? (o[r] - mn) / sc : 0.0f;
+    for (int r = 0; r < 4; ++r) y[r] = valid[r] ? div_r2(o[r] - mn, sc, rs) : 0.0f;
     return y;
 }
 
@@ -413,24 +426,6 @@ __device__ __forceinline__ void quad_representation(const Model& m, const QuadLd
 }
 
 /* ------------------------------------------------------------------ search */
-
-/* a / d given r = RN(1/d): product, then fma residual corrections (Markstein).  Each step
- * takes a faithful quotient to the correctly rounded one; one step is exhaustively verified for
- * fp32 with integer d <= 512 (tests/test_division.py), elsewhere two steps are used.  No
- * overflow / underflow on this path: operands are visit counts, values and priors. */
-__device__ __forceinline__ float div_r1(float a, float d, float r) {
-    const float q = a * r;
-    return mzs_fma(mzs_fma(-q, d, a), r, q);
-}
-__device__ __forceinline__ float div_r2(float a, float d, float r) {
-    const float q = div_r1(a, d, r);
-    return mzs_fma(mzs_fma(-q, d, a), r, q);
-}
-__device__ __forceinline__ double div_r2(double a, double d, double r) {
-    double q = a * r;
-    q = __builtin_fma(__builtin_fma(-q, d, a), r, q);
-    return __builtin_fma(__builtin_fma(-q, d, a), r, q);
-}
 
 struct QuadState {
     float mn, mx;       /* MinMaxStats of this lane's game        */

@@ -44,8 +44,8 @@ static void softmax(const float* q, int n, float* p, float* scratch) {
     for (int i = 1; i < n; ++i) m = q[i] > m ? q[i] : m;
     for (int i = 0; i < n; ++i) p[i] = mzs_expf(q[i] - m);
     memcpy(scratch, p, sizeof(float) * (size_t)n);
-    float Z = tree_sum(scratch, n);
-    for (int i = 0; i < n; ++i) p[i] = p[i] / Z;
+    float Z = tree_sum(scratch, n), rz = 1.0f / Z;
+    for (int i = 0; i < n; ++i) p[i] = mzs_div_r2(p[i], Z, rz); /* contract quotient (mzs_numeric.h) */
 }
 
 /* inverse_transform_with_support (muzero_model.py:571-587): softmax, expectation
@@ -69,8 +69,8 @@ void mzo_scale_to_bound(const float* x, int32_t n, float* y) {
         mn = x[i] < mn ? x[i] : mn;
         mx = x[i] > mx ? x[i] : mx;
     }
-    float sc = mzs_bound_scale(mn, mx);
-    for (int i = 0; i < n; ++i) y[i] = (x[i] - mn) / sc;
+    float sc = mzs_bound_scale(mn, mx), rs = 1.0f / sc;
+    for (int i = 0; i < n; ++i) y[i] = mzs_div_r2(x[i] - mn, sc, rs);
 }
 
 float mzo_expf(float x) { return mzs_expf(x); }

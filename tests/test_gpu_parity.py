@@ -219,6 +219,35 @@ def test_deep_searches_vs_oracle(shape, S):
     eng.close()
 
 
+@pytest.mark.parametrize("shape", [(4, 2, 31, 64, 0), (4, 2, 31, 64, 2), (6, 3, 21, 32, 1)])
+def test_saturated_logits_bit_exact(shape):
+    """Weights 10x the usual scale: logit spreads of several hundred, so softmax terms hit the
+    exp clamp and quotients can go subnormal — the corner of the contract's shared-reciprocal
+    quotient (mzs_div_r2) where it may differ from a correctly rounded division.  GPU (quad and
+    generic kernels) and oracle follow the same operation sequence: still bit-identical."""
+    from muzero_amd import rng
+    from muzero_amd.model import blob_layout
+    from oracle import mz_oracle as mzo
+    d = mzo.dims(*shape)
+    G, S = 23, 12
+    rs = np.random.RandomState(sum(shape))
+    n_w = sum(int(np.prod(shp)) for _, shp in blob_layout(*shape))
+    blob = (rs.standard_normal(n_w) * 3.0).astype(np.float32)
+    obs = rs.uniform(-1, 1, size=(G, shape[0])).astype(np.float32)
+    pol = mzo.prediction(d, blob, mzo.representation(d, blob, obs))[0]
+    assert pol.min() < 1e-30 and (pol > 0).all()               # saturated: terms at the exp clamp
+    dirichlet, noise = rng.noise_streams(np.arange(G) + 9, shape[1], S, 0.25, True)
+    for engine in ENGINES:
+        eng = make_engine(d, G, S, 0.997, engine=engine)
+        eng.set_weights(blob)
+        eng.search(obs, dirichlet, noise, S, True)
+        out, tree = eng.results_host(), eng.tree_host()
+        ref = mzo.search(d, blob, S, 0.997, 0.25, eng.pbc, obs=obs, dirichlet=dirichlet, noise=noise,
+                         train=True, want=FULL_WANT)
+        assert_search_equals_oracle(out, tree, ref)
+        eng.close()
+
+
 def test_full_size_4096_games_vs_oracle():
     """BASELINE config C2: 4096 games x 50 simulations, tag-123 weights, against the
     oracle on all games (bit-exact), plus size-independent invariants."""
