@@ -252,6 +252,20 @@ int mzs_arena_priority(mzs_arena* arena, int32_t row0, int32_t n_rows, int32_t t
 #define MZS_ARENA_SLOT_ROW 9   /* i32 [n_slots]                 row the slot records into */
 void* mzs_arena_array(mzs_arena* arena, int32_t which);
 
+/* ---- replay store, host side (CPU only; no GPU work, callable without a device).
+ * ReplayBuffer.sample_position + the mouve_prio lookup of sample_batch (replay_buffer.py:100-118,
+ * :155) for a batch: rows[b] / row_len[b] = prio_position of sample b's game; u[b] = the uniform
+ * number np.random.choice would draw (NULL: positions in pos[] are given, uniform position
+ * sampling); pos[b] <- the position, mouve[b] <- soft_prio_position[pos].  NumPy's float64
+ * arithmetic (pairwise sum, sequential cumsum, cdf / cdf[-1], searchsorted right) restated. */
+int mzs_replay_sample_positions(int32_t batch, const double* const* rows, const int32_t* row_len, const double* u,
+                                int64_t* pos, double* mouve);
+/* ReplayBuffer.update_value (replay_buffer.py:169-177): new_value [K][batch]; game_len[b] = the
+ * sampled game's game_length, game_idx[b] its buffer index into prio_game. */
+int mzs_replay_update_value(int32_t batch, int32_t num_unroll, double* const* rows, const int32_t* row_len,
+                            const int32_t* game_len, const int64_t* game_idx, const int64_t* pos,
+                            const double* new_value, double* prio_game);
+
 const char* mzs_last_error(void);
 const char* mzs_version(void);
 

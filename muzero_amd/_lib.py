@@ -89,6 +89,10 @@ _SIGNATURES = {
     "mzs_arena_priority": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_void_p]),
     "mzs_arena_array": (C.c_void_p, [C.c_void_p, C.c_int32]),
+    "mzs_replay_sample_positions": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                              C.c_void_p]),
+    "mzs_replay_update_value": (C.c_int, [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "mzs_last_error": (C.c_char_p, []),
     "mzs_version": (C.c_char_p, []),
 }

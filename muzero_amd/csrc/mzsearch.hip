@@ -20,6 +20,7 @@
 #include "mzs_quad.h"
 #include "mzs_train.h"
 #include "mzs_selfplay.h"
+#include "mzs_replay.h"
 
 using namespace mzs;
 
@@ -1573,6 +1574,30 @@ int mzs_arena_priority(mzs_arena* ar, int32_t row0, int32_t n_rows, int32_t td_s
                        static_cast<hipStream_t>(stream), ar->a, row0, n_rows, td_steps, discount_pow_dev,
                        out_stride, priority_dev);
     HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
+int mzs_replay_sample_positions(int32_t batch, const double* const* rows, const int32_t* row_len, const double* u,
+                                int64_t* pos, double* mouve) {
+    if (batch < 0 || (batch > 0 && (!rows || !row_len || !pos || !mouve))) return fail(MZS_E_ARG, "null argument");
+    const int bad = replay_sample_positions(batch, rows, row_len, u, pos, mouve);
+    if (bad) {
+        char msg[96];
+        std::snprintf(msg, sizeof msg, "sample %d: probabilities contain NaN or the position is out of range", bad - 1);
+        return fail(MZS_E_ARG, msg);
+    }
+    return MZS_OK;
+}
+
+int mzs_replay_update_value(int32_t batch, int32_t num_unroll, double* const* rows, const int32_t* row_len,
+                            const int32_t* game_len, const int64_t* game_idx, const int64_t* pos,
+                            const double* new_value, double* prio_game) {
+    if (batch < 0 || num_unroll < 0 ||
+        (batch > 0 && (!rows || !row_len || !game_len || !game_idx || !pos || !new_value || !prio_game)))
+        return fail(MZS_E_ARG, "null argument");
+    for (int32_t b = 0; b < batch; ++b)
+        if (row_len[b] < 1 || pos[b] < 0 || game_idx[b] < 0) return fail(MZS_E_ARG, "bad row length or position");
+    replay_update_value(batch, num_unroll, rows, row_len, game_len, game_idx, pos, new_value, prio_game);
     return MZS_OK;
 }
 

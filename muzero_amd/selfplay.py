@@ -103,7 +103,7 @@ class ReplayStore:
         consumes the generator identically (pinned by tests/test_selfplay_oracle.py)."""
 
     def __init__(self, window_size, batch_size, num_unroll, td_steps, game_sampling="priority",
-                 position_sampling="priority", discount=0.997, rng=None):
+                 position_sampling="priority", discount=0.997, rng=None, native=True):
         for m in (game_sampling, position_sampling):
             if m not in ("uniform", "priority"):
                 raise ValueError(f"sampling mode {m!r}")
@@ -119,7 +119,11 @@ class ReplayStore:
         self.big_n_of_importance_sampling_ratio = 0
         # prio_position: one [n, width] float64 block per save_games call + (block, index, length) per entry
         self._blocks, self._next_block = {}, 0
-        self._blk, self._bidx, self._plen = (np.zeros(0, np.int64) for _ in range(3))
+        self._blk, self._bidx, self._plen, self._addr = (np.zeros(0, np.int64) for _ in range(4))
+        # native=True: the per-sample loops of sample_batch / update_value run in the library
+        # (muzero_amd/csrc/mzs_replay.h: NumPy's float64 arithmetic restated, same results bit for
+        # bit); native=False: the NumPy formulation below, kept as the checked definition
+        self.lib = _lib.load() if native else None
 
     def __len__(self):
         return len(self.rows)
@@ -174,6 +178,7 @@ class ReplayStore:
             self._blk = np.concatenate([self._blk, np.full(m, bid, np.int64)])[pp:]
             self._bidx = np.concatenate([self._bidx, np.arange(m, dtype=np.int64)])[pp:]
             self._plen = np.concatenate([self._plen, lengths])[pp:]
+            self._addr = np.concatenate([self._addr, prio.ctypes.data + np.arange(m, dtype=np.int64) * prio.strides[0]])[pp:]
             for old in [k for k in self._blocks if len(self._blk) and k < int(self._blk[0])]:
                 del self._blocks[old]
             self.soft_prio_game = self.prio_game / np.sum(self.prio_game)
@@ -209,6 +214,17 @@ class ReplayStore:
             raise Exception("Game need to return at least one reward")
         prio_pos = self.position_sampling == "priority"
         u = self.rng.random_sample(B) if prio_pos else None
+        if self.lib is not None and self.uses_priority:
+            if not prio_pos:
+                for b in range(B):
+                    pos[b] = self.rng.randint(0, self.lengths[gi[b]] - 1)
+            rows = np.ascontiguousarray(self._addr[gi])
+            rlen = np.ascontiguousarray(self._plen[gi], np.int32)
+            p_ = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+            rc = self.lib.mzs_replay_sample_positions(B, p_(rows), p_(rlen), p_(u), p_(pos), p_(mouve))
+            if rc != 0:
+                raise ValueError(self.lib.mzs_last_error().decode())
+            return self._finish_batch(gi, pos, mouve)
         pp, cache = self.prio_position, {}
         for b in range(B):
             g = int(gi[b])
@@ -230,6 +246,9 @@ class ReplayStore:
                 pos[b] = self.rng.randint(0, self.lengths[g] - 1)
             if self.uses_priority:
                 mouve[b] = soft[pos[b]]
+        return self._finish_batch(gi, pos, mouve)
+
+    def _finish_batch(self, gi, pos, mouve):
         game_pos = np.stack([gi, pos], 1)
         row_pos = np.stack([self.rows[gi], pos], 1).astype(np.int32)
         if self.uses_priority:
@@ -241,9 +260,20 @@ class ReplayStore:
     def update_value(self, new_value, position):
         """update_value (replay_buffer.py:169-177); new_value [K][B] or [K][B][1]."""
         nv = np.asarray(new_value, np.float64)
-        nv = nv.reshape(nv.shape[0], nv.shape[1])
+        nv = np.ascontiguousarray(nv.reshape(nv.shape[0], nv.shape[1]))
+        position = np.asarray(position, np.int64)
+        if self.lib is not None:
+            gi, pos = np.ascontiguousarray(position[:, 0]), np.ascontiguousarray(position[:, 1])
+            rows = np.ascontiguousarray(self._addr[gi])
+            rlen = np.ascontiguousarray(self._plen[gi], np.int32)
+            glen = np.ascontiguousarray(self.lengths[gi], np.int32)
+            p_ = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+            _lib.check(self.lib.mzs_replay_update_value(len(gi), self.num_unroll, p_(rows), p_(rlen), p_(glen),
+                                                        p_(gi), p_(pos), p_(nv), p_(self.prio_game)),
+                       "mzs_replay_update_value")
+            return
         pp = self.prio_position
-        for count, (g, p) in enumerate(np.asarray(position, np.int64)):
+        for count, (g, p) in enumerate(position):
             hi = min(self.num_unroll + p, self.lengths[g] - 1)
             row = pp[g]
             if hi > p:

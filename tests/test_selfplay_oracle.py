@@ -105,14 +105,16 @@ def test_make_priority_many_rows():
                 assert np.array_equal(prio[r, :n], game(i)[f"prio_td{td}"])
 
 
+@pytest.mark.parametrize("native", [False, True])
 @pytest.mark.parametrize("ri", [0, 1])
-def test_replay_store_matches_reference_buffer(ri):
+def test_replay_store_matches_reference_buffer(ri, native):
     pre = f"rb{ri}_"
     window, td, B, K, pos_prio = (int(x) for x in FX[pre + "cfg"])
     pool = FX["rb_pool"].tolist()
     order = FX[pre + "order"].tolist()
     T = max(game(i)["visits"].shape[0] for i in pool) + 1
-    store = sp.ReplayStore(window, B, K, td, "priority", "priority" if pos_prio else "uniform", discount=0.997)
+    store = sp.ReplayStore(window, B, K, td, "priority", "priority" if pos_prio else "uniform", discount=0.997,
+                           native=native)
     # arena rows: one per save (the reference saves distinct Game objects)
     traj = []
     for step, o in enumerate(order):
@@ -153,6 +155,46 @@ def test_save_games_block_equals_one_by_one():
     assert all(np.array_equal(x, y) for x, y in zip(a.prio_position, b.prio_position)) and len(a._blocks) == 1
     assert a.big_n_of_importance_sampling_ratio == b.big_n_of_importance_sampling_ratio == sum(a.lengths)
     assert np.array_equal(a.soft_prio_game, b.soft_prio_game)
+
+
+@pytest.mark.parametrize("pos_mode", ["priority", "uniform"])
+def test_native_replay_loops_equal_numpy(pos_mode):
+    """The library's host loops (mzs_replay.h: NumPy's pairwise sum / cumsum / searchsorted restated)
+    against the NumPy formulation on a large random store: same draws, same ratios, same
+    priorities after update_value, bit for bit, over many steps (game lengths 2..400 cover every
+    branch of the pairwise summation: < 8, <= 128, recursive)."""
+    rs = np.random.RandomState(7)
+    n, T, B, K = 3000, 400, 128, 5
+    lengths = rs.randint(2, T + 1, n)
+    lengths[:40] = rs.randint(2, 9, 40)
+    prio = np.abs(rs.standard_normal((n, T))) * rs.choice([1e-3, 1.0, 50.0], (n, 1))
+    prio[np.arange(T)[None, :] >= lengths[:, None]] = 0.0
+    # window overflow only under priority / priority: with uniform positions the reference pops
+    # prio_game but not prio_position (replay_buffer.py:64-67) and then indexes out of range
+    window = 2500 if pos_mode == "priority" else 4000
+    stores = [sp.ReplayStore(window, B, K, 10, "priority", pos_mode, native=nat) for nat in (False, True)]
+    for st in stores:
+        st.save_games(np.arange(n), lengths, priorities=prio.copy())
+    for step in range(30):
+        outs = []
+        for st in stores:
+            np.random.seed(100 + step)
+            outs.append(st.sample_batch())
+        for a, b in zip(*outs):
+            assert np.array_equal(a, b)
+        newp = np.abs(np.random.RandomState(step).standard_normal((K, B))) * 3
+        for st in stores:
+            st.update_value(newp, outs[0][2])
+        assert np.array_equal(stores[0].prio_game, stores[1].prio_game)
+    for a, b in zip(stores[0].prio_position, stores[1].prio_position):
+        assert np.array_equal(a, b)
+    if pos_mode == "priority":
+        for st in stores:                                     # an all-zero row: np.random.choice raises
+            st.prio_position[5][:] = 0.0
+            st.soft_prio_game[:] = 0.0
+            st.soft_prio_game[5] = 1.0
+            with pytest.raises(ValueError):
+                st.sample_batch()
 
 
 def test_temperature_scheduler():
