@@ -182,6 +182,7 @@ class ReplayStore:
             for old in [k for k in self._blocks if len(self._blk) and k < int(self._blk[0])]:
                 del self._blocks[old]
             self.soft_prio_game = self.prio_game / np.sum(self.prio_game)
+            self._game_cdf = None          # cdf of soft_prio_game, built by the first sample_batch after a save
         self.rows = np.concatenate([self.rows, rows])[pops:]
         self.lengths = np.concatenate([self.lengths, lengths])[pops:]
         self.big_n_of_importance_sampling_ratio = int(self.lengths.sum())
@@ -205,7 +206,14 @@ class ReplayStore:
         (buffer index, position) as the reference returns it)."""
         B = self.batch_size
         if self.game_sampling == "priority":
-            gi = self._choice(self.soft_prio_game, self.rng.random_sample(B))
+            # np.random.choice(range(n), p=soft_prio_game) B times; soft_prio_game only changes in
+            # save_games (replay_buffer.py:80), so its validated cdf is kept between batches
+            if getattr(self, "_game_cdf", None) is None or len(self._game_cdf) != len(self.soft_prio_game):
+                self._choice(self.soft_prio_game, np.zeros(1))
+                cdf = np.cumsum(self.soft_prio_game)
+                cdf /= cdf[-1]
+                self._game_cdf = cdf
+            gi = self._game_cdf.searchsorted(self.rng.random_sample(B), side="right")
         else:
             gi = self.rng.randint(0, len(self.rows), size=B)
         pos = np.zeros(B, np.int64)

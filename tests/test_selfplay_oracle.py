@@ -193,6 +193,7 @@ def test_native_replay_loops_equal_numpy(pos_mode):
             st.prio_position[5][:] = 0.0
             st.soft_prio_game[:] = 0.0
             st.soft_prio_game[5] = 1.0
+            st._game_cdf = None                               # (the cached cdf follows save_games only)
             with pytest.raises(ValueError):
                 st.sample_batch()
 
