@@ -247,3 +247,32 @@ def test_learning_cycle_from_reference_config(tmp_path):
     assert len(rewards) == 3 and all(np.isfinite(losses)) and len(loop.store) == 1501
     assert loop.trainer.count == 3
     loop.arena.close(), loop.eng.close()
+
+
+def test_arena_errors_are_loud():
+    """Bad arguments come back as error codes with a message (never a fault on the GPU)."""
+    import ctypes as C
+    import torch
+    from muzero_amd import _lib
+    from muzero_amd.selfplay import Arena
+    lib = _lib.load()
+    eng, dims, _ = make_engine(8, 0)
+    h = C.c_void_p()
+    for cfg in (_lib.ArenaConfig(0, 7, 8, 8, 10), _lib.ArenaConfig(0, 0, 0, 8, 10), _lib.ArenaConfig(0, 0, 8, 4, 10),
+                _lib.ArenaConfig(0, 0, 8, 8, 0)):
+        assert lib.mzs_arena_create(C.byref(cfg), C.byref(h)) != 0 and lib.mzs_last_error()
+    ar = Arena(eng, 8, 16, 10)
+    with pytest.raises(ValueError):
+        ar.begin(10, np.arange(8), 0)                       # rows 10..17 do not exist
+    with pytest.raises(ValueError):
+        ar.begin(0, np.zeros(0, np.int64), 0)
+    seeds = torch.arange(8, dtype=torch.int64, device=eng.device)
+    assert lib.mzs_arena_begin(ar.h, 12, 8, C.c_void_p(seeds.data_ptr()), 0, C.c_void_p(ar.obs.data_ptr()), None) != 0
+    assert lib.mzs_arena_begin(ar.h, 0, 8, None, 0, C.c_void_p(ar.obs.data_ptr()), None) != 0
+    assert lib.mzs_arena_step(ar.h, None, None, None, C.c_double(0.0), 50, None, None, None) != 0
+    assert lib.mzs_arena_priority(ar.h, 8, 16, 3, None, 10, None, None) != 0
+    assert lib.mzs_arena_make_batch(ar.h, 4, None, 5, 3, None, None, None, None, None, None, None) != 0
+    assert lib.mzs_arena_array(ar.h, 99) is None
+    with pytest.raises(ValueError):
+        Arena(eng, 9, 16, 10)                               # more slots than the engine searches at once
+    ar.close(), eng.close()
