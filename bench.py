@@ -45,6 +45,8 @@ def search_kernel_name(obs_dim, A, S_dim, H, L, kind):
     shape = (S_dim, A, H)
     quad = kind == 0 and obs_dim <= 64 and shape in ((31, 2, 64), (31, 3, 64), (31, 4, 64), (11, 2, 16))
     mid = "true" if L > 0 else "false"
+    if kind == 0 and obs_dim <= 64 and (S_dim, A, H) == (61, 2, 128):
+        return "k_search_quadw<61,2,128>"
     return f"k_search_quad<{S_dim},{A},{H},false,{mid}>" if quad else "k_search_fused<false>"
 
 

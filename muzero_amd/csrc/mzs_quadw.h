@@ -1,0 +1,261 @@
+/*
+ * mzs_quadw.h — the four-games-per-wavefront search for MLPs too wide for register-resident
+ * weights (experiments 127 / 128: S_dim 61, H 128, L 1 = 1268 weight rows per simulation).
+ *
+ * Same lane roles, tree code and arithmetic as mzs_quad.h (bit for bit: include/mzs_numeric.h);
+ * what changes is where the operands live:
+ *   A operand (weights)  streamed from the device weight store (L2-resident, 324 KB for the shape
+ *                        above): one coalesced 256-byte row per MFMA, shared by the four games —
+ *                        a quarter of the traffic of the one-game-per-wave generic kernel
+ *   outputs              H_pad / 64 groups of 64 neurons, one f32x4 accumulator pair each
+ *   hidden states        in HBM / L2 (the SoA output array the search fills anyway): 13 KB per
+ *                        game would not fit LDS next to the trees of sixteen games
+ *   heads                one 64-neuron group per head (reward | next state, policy | value at
+ *                        column 64 of the fused head layers), reduced over all sixteen lanes of a
+ *                        game: half_sum of each half, then the two halves — the contract's
+ *                        adjacent-pair tree over a segment padded to 64
+ * Compile-time S_dim (32 < S_dim <= 64), H (<= 128) and A, so that every weight row is a
+ * constant offset from a wave-uniform base (no per-load address arithmetic) and the fan-in tails
+ * generate no guards; obs_dim <= 64 and the number of tied mid layers are runtime values.
+ *
+ * Reference code restated (file:line in /root/reference): as mzs_device.h.
+ */
+#ifndef MZS_QUADW_H
+#define MZS_QUADW_H
+
+#include "mzs_quad.h"
+
+namespace mzs {
+
+constexpr int kWideTrunk = 128; /* floats per game in the trunk buffer */
+constexpr int kWideX = 64;      /* floats per game in the input (hidden state / observation) buffer */
+
+struct WideBufs {
+    float* xin;   /* [4][kWideX]     */
+    float* trunk; /* [4][kWideTrunk] */
+};
+
+__device__ __forceinline__ float game_sum(float v) {
+    v = half_sum(v);
+    float lo, hi;
+    halves_pair(v, lo, hi);
+    return lo + hi;
+}
+
+/* MFMA steps k = k0 + 16 kb + j, j < 16, of a chunk whose weight rows sit in wk; K is the layer's
+ * fan-in (compile time: rows past it do not exist and generate no code) */
+template <int K, int k0, int kb>
+__device__ __forceinline__ void wide_mfma16(const float (&wk)[64], const float (&x)[16], f32x4& e, f32x4& o) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        if (k0 + 16 * kb + j < K) {
+            if (j & 1)
+                o = __builtin_amdgcn_mfma_f32_4x4x1f32(wk[16 * kb + j], x[j], o, 0, 0, 4 + kb);
+            else
+                e = __builtin_amdgcn_mfma_f32_4x4x1f32(wk[16 * kb + j], x[j], e, 0, 0, 4 + kb);
+        }
+    }
+}
+
+typedef const __attribute__((address_space(1))) float* WideGlobalPtr; /* keeps global_load (not flat) after the asm */
+
+template <int K, int NPAD, int k0>
+__device__ __forceinline__ void wide_chunks(WideGlobalPtr row0, unsigned n, const float* xrow,
+                                            const QuadLane& q, f32x4& e, f32x4& o) {
+    if constexpr (k0 < K) {
+        /* one wave per SIMD hides nothing: all rows of the chunk are requested before the first
+         * MFMA.  row0 is wave-uniform (scalar base), n the lane's column, the row stride a constant */
+        float wk[64];
+#pragma unroll
+        for (int j = 0; j < 64; ++j) {
+            /* scalar base + zero-extended 32-bit lane offset: the saddr form of global_load */
+            WideGlobalPtr rk = row0 + (size_t)(k0 + j) * NPAD;
+            if (k0 + j < K) wk[j] = rk[n];
+        }
+        float x[16];
+        quad_load_x(xrow + k0, q.grp, x);
+        wide_mfma16<K, k0, 0>(wk, x, e, o);
+        wide_mfma16<K, k0, 1>(wk, x, e, o);
+        wide_mfma16<K, k0, 2>(wk, x, e, o);
+        wide_mfma16<K, k0, 3>(wk, x, e, o);
+        __builtin_amdgcn_sched_barrier(0); /* keep the next chunk's 64 loads behind this chunk's MFMAs */
+        wide_chunks<K, NPAD, k0 + 64>(row0, n, xrow, q, e, o);
+    }
+}
+
+/* contract "dot" of output group `grp` of a layer (W^T at wl, row stride NPAD, bias at bl) for the
+ * four games: K inputs from the game's LDS row xrow (a buffer of at least round_up(K, 64) floats) */
+template <int K, int NPAD>
+__device__ __forceinline__ f32x4 wide_dense(const float* __restrict__ wl, const float* __restrict__ bl, int grp,
+                                            const float* xrow, const QuadLane& q) {
+    const float4 bv = *reinterpret_cast<const float4*>(bl + 64 * grp + q.n0);
+    f32x4 e = f32x4{bv.x, bv.y, bv.z, bv.w}, o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    /* the layer base stays a scalar the optimiser cannot look through: otherwise it hoists the
+     * address of every weight row of every layer out of the simulation loop (as loop invariants,
+     * in vector register pairs) and spills them */
+    WideGlobalPtr base = (WideGlobalPtr)(wl + 64 * grp);
+    asm volatile("" : "+s"(base));
+    wide_chunks<K, NPAD, 0>(base, (unsigned)quad_neuron_of_lane(q.lane), xrow, q, e, o);
+    return e + o;
+}
+
+/* trunk layer (all NPAD / 64 output groups) + ELU -> the game's trunk row.  extra_row >= 0: add
+ * that row of W^T after the chains (the one-hot action column, per game).  The accumulators of
+ * every group are complete before the row is overwritten (the mid layer reads and writes the
+ * same buffer). */
+template <int K, int NPAD>
+__device__ __forceinline__ void wide_trunk(const float* __restrict__ w, const Layer ly, const float* xrow,
+                                           int extra_row, float* trunk_row, const QuadLane& q) {
+    constexpr int NG = NPAD / 64;
+    f32x4 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        acc[g] = wide_dense<K, NPAD>(w + ly.w_off, w + ly.b_off, g, xrow, q);
+        if (extra_row >= 0) {
+            const float4 c = *reinterpret_cast<const float4*>(w + ly.w_off + (size_t)extra_row * NPAD + 64 * g + q.n0);
+            acc[g] = f32x4{acc[g][0] + c.x, acc[g][1] + c.y, acc[g][2] + c.z, acc[g][3] + c.w};
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) store4(trunk_row + 64 * g + q.n0, elu4(acc[g]));
+    wave_sync();
+}
+
+struct WideValid {
+    bool v[4];
+};
+__device__ __forceinline__ WideValid wide_valid(const QuadLane& q, int n) {
+    WideValid r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r.v[i] = q.n0 + i < n;
+    return r;
+}
+
+/* softmax over the n valid logits of a 64-neuron group (contract exp + sum + shared-reciprocal quotient) */
+__device__ __forceinline__ f32x4 wide_softmax(const f32x4 o, const WideValid& vd) {
+    const float ninf = -__builtin_inff();
+    const float m = game_max(max4(f32x4{vd.v[0] ? o[0] : ninf, vd.v[1] ? o[1] : ninf, vd.v[2] ? o[2] : ninf,
+                                        vd.v[3] ? o[3] : ninf}));
+    f32x4 e;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const float ex = mzs_expf(o[r] - m);
+        e[r] = vd.v[r] ? ex : 0.0f;
+    }
+    const float Z = game_sum(sum4(e));
+    const float rz = 1.0f / Z;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) e[r] = div_r2(e[r], Z, rz);
+    return e;
+}
+
+/* expectation over the support i - n/2 (before the inverse value transform) */
+__device__ __forceinline__ float wide_support_mean(const f32x4 p, const WideValid& vd, const QuadLane& q, int n) {
+    f32x4 t;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) t[r] = vd.v[r] ? (float)(q.n0 + r - n / 2) * p[r] : 0.0f;
+    return game_sum(sum4(t));
+}
+
+__device__ __forceinline__ f32x4 wide_scale_to_bound(const f32x4 o, const WideValid& vd) {
+    const float ninf = -__builtin_inff();
+    const float mx = game_max(max4(f32x4{vd.v[0] ? o[0] : ninf, vd.v[1] ? o[1] : ninf, vd.v[2] ? o[2] : ninf,
+                                         vd.v[3] ? o[3] : ninf}));
+    const float mn = -game_max(max4(f32x4{vd.v[0] ? -o[0] : ninf, vd.v[1] ? -o[1] : ninf, vd.v[2] ? -o[2] : ninf,
+                                          vd.v[3] ? -o[3] : ninf}));
+    const float sc = mzs_bound_scale(mn, mx), rs = 1.0f / sc;
+    f32x4 y;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = vd.v[r] ? div_r2(o[r] - mn, sc, rs) : 0.0f;
+    return y;
+}
+
+/* the tied mid layer, m.L times, in place on the trunk row */
+template <int H>
+__device__ __forceinline__ void wide_mid(const Model& m, const Layer ly, float* trunk_row, const QuadLane& q) {
+    constexpr int HP = (H + 63) / 64 * 64;
+    for (int l = 0; l < m.L; ++l) wide_trunk<H, HP>(m.w, ly, trunk_row, -1, trunk_row, q);
+}
+
+/* Representation_function: observation in the game's xin row -> hidden state in the xin row and in
+ * the global row hdst.  Root only: the observation width stays a runtime value (padded to 64 zero
+ * inputs, whose products add +0 to chains that start at a bias: no effect on any bit unless a bias
+ * is -0, which weights_init and training never produce). */
+template <int SD, int H>
+__device__ __forceinline__ void wide_representation(const Model& m, const WideBufs& B, const QuadLane& q, float* hdst) {
+    constexpr int HP = (H + 63) / 64 * 64;
+    float* xrow = B.xin + q.c * kWideX;
+    float* trow = B.trunk + q.c * kWideTrunk;
+    {
+        constexpr int NG = HP / 64;
+        f32x4 acc[NG];
+        const int n = quad_neuron_of_lane(q.lane);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float4 bv = *reinterpret_cast<const float4*>(m.w + m.r_in.b_off + 64 * g + q.n0);
+            f32x4 e = f32x4{bv.x, bv.y, bv.z, bv.w}, o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+            for (int k = 0; k < m.obs_dim; ++k) {
+                const float wk = m.w[m.r_in.w_off + (size_t)k * HP + 64 * g + n], xk = xrow[k];
+                if (k & 1)
+                    o = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, xk, o, 0, 0, 0);
+                else
+                    e = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, xk, e, 0, 0, 0);
+            }
+            acc[g] = e + o;
+        }
+        wave_sync();
+#pragma unroll
+        for (int g = 0; g < NG; ++g) store4(trow + 64 * g + q.n0, elu4(acc[g]));
+        wave_sync();
+    }
+    wide_mid<H>(m, m.r_mid, trow, q);
+    const f32x4 acc = wide_dense<H, 64>(m.w + m.r_out.w_off, m.w + m.r_out.b_off, 0, trow, q);
+    const f32x4 y = wide_scale_to_bound(acc, wide_valid(q, SD));
+    wave_sync();
+    store4(xrow + q.n0, y);
+    store4(hdst + q.n0, y);
+    wave_sync();
+}
+
+/* Dynamics_function on the hidden state in the game's xin row + action: the new hidden state
+ * replaces it (and goes to the global row hdst); returns the reward's support expectation */
+template <int SD, int H>
+__device__ __forceinline__ float wide_dynamics(const Model& m, const WideBufs& B, const QuadLane& q, int action,
+                                               float* hdst) {
+    constexpr int HP = (H + 63) / 64 * 64;
+    float* xrow = B.xin + q.c * kWideX;
+    float* trow = B.trunk + q.c * kWideTrunk;
+    wide_trunk<SD, HP>(m.w, m.d_in, xrow, SD + action, trow, q);
+    wide_mid<H>(m, m.d_mid, trow, q);
+    const WideValid vd = wide_valid(q, SD);
+    const f32x4 ar = wide_dense<H, 128>(m.w + m.d_heads.w_off, m.w + m.d_heads.b_off, 0, trow, q);
+    const float reward = wide_support_mean(wide_softmax(ar, vd), vd, q, SD);
+    const f32x4 as = wide_dense<H, 128>(m.w + m.d_heads.w_off, m.w + m.d_heads.b_off, 1, trow, q);
+    const f32x4 y = wide_scale_to_bound(as, vd);
+    wave_sync();
+    store4(xrow + q.n0, y);
+    store4(hdst + q.n0, y);
+    wave_sync();
+    return reward;
+}
+
+/* Prediction_function on the hidden state in the game's xin row: priors of actions 0..3 in the
+ * lanes with n0 == 0; returns the value's support expectation */
+template <int SD, int H>
+__device__ __forceinline__ float wide_prediction(const Model& m, const WideBufs& B, const QuadLane& q, int n_actions,
+                                                 f32x4* prior) {
+    constexpr int HP = (H + 63) / 64 * 64;
+    float* xrow = B.xin + q.c * kWideX;
+    float* trow = B.trunk + q.c * kWideTrunk;
+    wide_trunk<SD, HP>(m.w, m.p_in, xrow, -1, trow, q);
+    wide_mid<H>(m, m.p_mid, trow, q);
+    const f32x4 ap = wide_dense<H, 128>(m.w + m.p_heads.w_off, m.w + m.p_heads.b_off, 0, trow, q);
+    *prior = wide_softmax(ap, wide_valid(q, n_actions));
+    const WideValid vd = wide_valid(q, SD);
+    const f32x4 av = wide_dense<H, 128>(m.w + m.p_heads.w_off, m.w + m.p_heads.b_off, 1, trow, q);
+    return wide_support_mean(wide_softmax(av, vd), vd, q, SD);
+}
+
+}  // namespace mzs
+#endif

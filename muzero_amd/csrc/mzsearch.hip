@@ -18,6 +18,7 @@
 #include "../../include/mzsearch.h"
 #include "mzs_device.h"
 #include "mzs_quad.h"
+#include "mzs_quadw.h"
 #include "mzs_train.h"
 #include "mzs_selfplay.h"
 #include "mzs_replay.h"
@@ -448,6 +449,157 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
 }
 
 /* ------------------------------------------------------------------------------
+ * k_search_quadw: four games per wave for wide MLPs (mzs_quadw.h): weights streamed from the
+ * store, hidden states in the global SoA array, trees in LDS.  Same search code as k_search_quad.
+ * ---------------------------------------------------------------------------- */
+template <int SD, int NA, int H>
+__global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, const QuadLayout ql) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const QuadLane q = quad_lane();
+    const int wave = threadIdx.x >> 6;
+    const Model& m = p.m;
+    const int S = p.S;
+
+    double* pbc_s = reinterpret_cast<double*>(smem);
+    double* inv64_s = reinterpret_cast<double*>(smem + ql.off_inv64);
+    float* inv32_s = reinterpret_cast<float*>(smem + ql.off_inv32);
+    for (int i = threadIdx.x; i < S + 2; i += blockDim.x) {
+        pbc_s[i] = p.pbc[i];
+        inv64_s[i] = 1.0 / (double)(i > 0 ? i : 1);
+        inv32_s[i] = 1.0f / (float)(i > 0 ? i : 1);
+    }
+    __syncthreads();
+
+    const int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 4;
+    if (g0 >= p.n_games) return;
+    const bool live = g0 + q.c < p.n_games;
+    const int g = live ? g0 + q.c : p.n_games - 1;
+
+    unsigned char* wbase = smem + ql.shared_bytes + (size_t)wave * ql.wave_bytes;
+    unsigned char* gbase = wbase + ql.off_games + (size_t)q.c * ql.g_bytes;
+    WideBufs B;
+    B.trunk = reinterpret_cast<float*>(wbase);
+    B.xin = reinterpret_cast<float*>(wbase + 4 * kWideTrunk * 4);
+    QuadLds L;
+    L.trunk = B.trunk;
+    L.nwin = reinterpret_cast<double*>(wbase + ql.off_nwin);
+    L.onehot = nullptr;
+    L.pbc = pbc_s;
+    L.inv64 = inv64_s;
+    L.inv32 = inv32_s;
+    L.nodes = reinterpret_cast<QNode*>(gbase);
+    L.vsum = reinterpret_cast<float*>(gbase + ql.g_vsum);
+    L.path = reinterpret_cast<uint2*>(gbase + ql.g_path);
+    L.hid = nullptr;
+    L.leafs = reinterpret_cast<unsigned short*>(gbase + ql.g_leafs);
+
+    const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
+    const int noise_cap = p.noise ? (int)p.noise_stride : 0;
+    float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * p.t.hid_stride;
+    float* xrow = B.xin + q.c * kWideX;
+
+    QuadState s;
+    s.mn = __builtin_inff();
+    s.mx = -__builtin_inff();
+    s.rinv = 0.0f;
+    s.rootp = 0.0;
+    s.consumed = 0;
+    s.path_total = 0;
+    s.status = 0;
+
+    for (int n = q.b; n < p.n_nodes; n += 16) {
+        QNode z;
+        z.vc = 0u;
+        z.x0 = 0.0f;
+        z.prior = 0.0f;
+        z.reward = 0.0f;
+        L.nodes[n] = z;
+        L.vsum[n] = 0.0f;
+    }
+    if (q.b == 0) L.path[0] = make_uint2(0u, 0u);
+    double nz = S > 0 ? quad_noise_prefetch<NA>(s, q, noise, noise_cap) : 0.0;
+
+    /* root: representation -> prediction -> expand (mcts.py:88-123) */
+    f32x4 pr;
+    for (int k = q.b; k < kWideX; k += 16) xrow[k] = k < m.obs_dim ? p.obs[(size_t)g * m.obs_dim + k] : 0.0f;
+    wave_sync();
+    wide_representation<SD, H>(m, B, q, hid_g);
+    (void)wide_prediction<SD, H>(m, B, q, NA, &pr);
+    if (q.b == 0) {
+#pragma unroll
+        for (int r = 0; r < NA; ++r) L.nodes[1 + r].prior = pr[r];
+        L.nodes[0].vc = 1u;
+    }
+    wave_sync();
+    {
+        constexpr int NAL = NA <= 2 ? 2 : 4;
+        const int a = q.b & (NAL - 1);
+        if (a < NA) {
+            const float pa = L.nodes[1 + a].prior;
+            if (p.train && S > 0)
+                s.rootp = (double)(pa * p.omf32) + p.dirichlet[(size_t)g * NA + a] * p.frac;
+            else
+                s.rootp = (double)pa;
+        }
+    }
+
+    for (int sim = 0; sim < S; ++sim) {
+        L.nwin[q.lane] = nz;
+        wave_sync();
+        const QuadSelect<NA> sel = quad_select<NA>(L, s, q, noise, noise_cap, sim);
+        nz = quad_noise_prefetch<NA>(s, q, noise, noise_cap);
+        const int e_new = sim + 1;
+        /* the parent's hidden state: 64 floats per game, four per lane */
+        const int e_parent = (sel.pbase - 1) / NA;
+        const float4 hv = *reinterpret_cast<const float4*>(hid_g + (size_t)e_parent * p.t.hid_stride + 4 * q.b);
+        *reinterpret_cast<float4*>(xrow + 4 * q.b) = hv;
+        wave_sync();
+        const float yr = wide_dynamics<SD, H>(m, B, q, sel.action, hid_g + (size_t)e_new * p.t.hid_stride);
+        const float yv = wide_prediction<SD, H>(m, B, q, NA, &pr);
+        float reward, value;
+        halves_pair(quad_inverse_value_transform(q.half ? yv : yr), reward, value);
+        const int cbase = 1 + e_new * NA;
+        if (q.b == 0) {
+#pragma unroll
+            for (int r = 0; r < NA; ++r) L.nodes[cbase + r].prior = pr[r];
+            L.nodes[sel.leaf].reward = reward;
+            L.nodes[sel.leaf].vc = (unsigned)cbase;
+            L.leafs[sim] = (unsigned short)sel.leaf;
+            L.path[sel.depth].y = __float_as_uint(reward);
+        }
+        wave_sync();
+        quad_backup(L, s, q, sel.depth, value, p.g32);
+    }
+
+    if (live) {
+        const size_t row = (size_t)g * p.t.stride;
+        for (int n = q.b; n < p.n_nodes; n += 16) {
+            const QNode nd = L.nodes[n];
+            p.t.visit[row + n] = (int)(nd.vc >> 16);
+            p.t.vsum[row + n] = L.vsum[n];
+            p.t.prior[row + n] = nd.prior;
+            p.t.reward[row + n] = nd.reward;
+            p.t.child_base[row + n] = (int)(nd.vc & 0xffffu);
+        }
+        for (int i = q.b; i < S; i += 16) p.t.sim_leaf[(size_t)g * p.t.max_sims + i] = L.leafs[i];
+        constexpr int NAL = NA <= 2 ? 2 : 4;
+        if (q.b < NAL && q.b < NA) {
+            p.r.visits[(size_t)g * NA + q.b] = (int)(L.nodes[1 + q.b].vc >> 16);
+            p.r.root_prior[(size_t)g * NA + q.b] = s.rootp;
+        }
+        if (q.b == 0) {
+            const int rv = (int)(L.nodes[0].vc >> 16);
+            p.r.root_value[g] = rv == 0 ? 0.0f : L.vsum[0] / (float)rv;
+            p.r.consumed[g] = s.consumed;
+            p.r.path_len[g] = s.path_total;
+            p.t.minmax[2 * (size_t)g] = s.mn;
+            p.t.minmax[2 * (size_t)g + 1] = s.mx;
+            p.t.status[g] = s.status;
+        }
+    }
+}
+
+/* ------------------------------------------------------------------------------
  * Standalone batched inference (wave per sample): the Muzero.*_inference wrappers
  * (muzero_model.py:828-905).
  * ---------------------------------------------------------------------------- */
@@ -743,7 +895,7 @@ void describe_model(const mzs_dims& d, Model* m, StoreBuilder* sb) {
     m->L = d.n_mid_layers;
     m->kind = d.model_kind;
     m->seg_state = round_up(Sd, 32);
-    m->seg_value = round_up(A, 32);
+    m->seg_value = Sd > 32 ? 64 : round_up(A, 32); /* wide heads: one 64-neuron group each (mzs_quadw.h) */
     if (d.model_kind == MZS_MODEL_LSTM) {
         const Layer none{0, 0, 0, 0};
         m->r_mid = m->r_out = m->d_in = m->d_mid = m->d_heads = m->p_in = m->p_mid = m->p_heads = none;
@@ -839,6 +991,29 @@ QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model) {
     return l;
 }
 
+/* LDS plan of k_search_quadw: trunk [4][128] and xin [4][64] per wave, trees per game, no hidden
+ * states (they live in the global SoA array) */
+QuadLayout make_quadw_layout(int n_nodes, int S) {
+    QuadLayout l;
+    l.off_inv64 = round_up((S + 2) * 8, 16);
+    l.off_inv32 = 2 * l.off_inv64;
+    l.off_onehot = l.off_inv32 + round_up((S + 2) * 4, 16);
+    l.shared_bytes = l.off_onehot;
+    l.off_nwin = 4 * kWideTrunk * 4 + 4 * kWideX * 4;
+    l.off_games = l.off_nwin + 64 * 8;
+    int off = n_nodes * (int)sizeof(QNode);
+    l.g_vsum = off;
+    off += round_up(n_nodes * 4, 16);
+    l.g_path = off;
+    off += round_up((S + 2) * 8, 16);
+    l.g_hid = off;
+    l.g_leafs = off;
+    off += round_up((S + 1) * 2, 16);
+    l.g_bytes = off;
+    l.wave_bytes = l.off_games + 4 * l.g_bytes;
+    return l;
+}
+
 /* the (S_dim, A, H) shapes the four-games-per-wave kernel is instantiated for */
 typedef void (*quad_kernel_t)(const SearchParams, const QuadLayout);
 quad_kernel_t pick_quad_kernel(const mzs_dims& d) {
@@ -854,6 +1029,13 @@ quad_kernel_t pick_quad_kernel(const mzs_dims& d) {
     }
     if (d.state_dim == 11 && d.n_actions == 2 && d.hidden_dim == 16)
         return mid ? k_search_quad<11, 2, 16, false, true> : k_search_quad<11, 2, 16, false, false>;
+    return nullptr;
+}
+
+/* wide MLPs (mzs_quadw.h): the shape of experiments 127 / 128 */
+quad_kernel_t pick_quadw_kernel(const mzs_dims& d) {
+    if (d.model_kind != MZS_MODEL_MLP || d.obs_dim > 64) return nullptr;
+    if (d.state_dim == 61 && d.hidden_dim == 128 && d.n_actions == 2) return k_search_quadw<61, 2, 128>;
     return nullptr;
 }
 
@@ -1091,6 +1273,11 @@ int mzs_search(mzs_handle* h, int32_t n_games, int32_t S, int32_t train, const f
     if (h->cfg.engine == MZS_ENGINE_FUSED && mzs_max_draws(h->cfg.dims.n_actions, S) < (1ll << 31)) {
         if (quad_kernel_t qk = pick_quad_kernel(h->cfg.dims)) {
             const QuadLayout ql = make_quad_layout(p.m.A, p.n_nodes, S, true);
+            const int wpb = quad_waves_per_block(ql);
+            if (wpb > 0) return launch_quad(qk, p, ql, wpb, static_cast<hipStream_t>(stream));
+        }
+        if (quad_kernel_t qk = pick_quadw_kernel(h->cfg.dims)) {
+            const QuadLayout ql = make_quadw_layout(p.n_nodes, S);
             const int wpb = quad_waves_per_block(ql);
             if (wpb > 0) return launch_quad(qk, p, ql, wpb, static_cast<hipStream_t>(stream));
         }
