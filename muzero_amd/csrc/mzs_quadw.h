@@ -60,26 +60,32 @@ __device__ __forceinline__ void wide_mfma16(const float (&wk)[64], const float (
 typedef const __attribute__((address_space(1))) float* WideGlobalPtr; /* keeps global_load (not flat) after the asm */
 
 template <int K, int NPAD, int k0>
-__device__ __forceinline__ void wide_chunks(WideGlobalPtr row0, unsigned n, const float* xrow,
-                                            const QuadLane& q, f32x4& e, f32x4& o) {
-    if constexpr (k0 < K) {
-        /* one wave per SIMD hides nothing: all rows of the chunk are requested before the first
-         * MFMA.  row0 is wave-uniform (scalar base), n the lane's column, the row stride a constant */
-        float wk[64];
+__device__ __forceinline__ void wide_load_chunk(WideGlobalPtr row0, unsigned n, float (&wk)[64]) {
 #pragma unroll
-        for (int j = 0; j < 64; ++j) {
-            /* scalar base + zero-extended 32-bit lane offset: the saddr form of global_load */
-            WideGlobalPtr rk = row0 + (size_t)(k0 + j) * NPAD;
-            if (k0 + j < K) wk[j] = rk[n];
-        }
+    for (int j = 0; j < 64; ++j) {
+        /* scalar base + zero-extended 32-bit lane offset: the saddr form of global_load */
+        WideGlobalPtr rk = row0 + (size_t)(k0 + j) * NPAD;
+        if (k0 + j < K) wk[j] = rk[n];
+    }
+}
+
+/* chunk k0 (its weight rows already requested into wk) and the chunks after it: the next chunk's
+ * 64 rows are requested before this chunk's MFMAs, so their latency overlaps 512 cycles of matrix
+ * work (one wave per SIMD hides nothing by itself) */
+template <int K, int NPAD, int k0>
+__device__ __forceinline__ void wide_chunks(WideGlobalPtr row0, unsigned n, const float* xrow,
+                                            const QuadLane& q, float (&wk)[64], f32x4& e, f32x4& o) {
+    if constexpr (k0 < K) {
+        float wn[64];
+        if constexpr (k0 + 64 < K) wide_load_chunk<K, NPAD, k0 + 64>(row0, n, wn);
         float x[16];
         quad_load_x(xrow + k0, q.grp, x);
         wide_mfma16<K, k0, 0>(wk, x, e, o);
         wide_mfma16<K, k0, 1>(wk, x, e, o);
         wide_mfma16<K, k0, 2>(wk, x, e, o);
         wide_mfma16<K, k0, 3>(wk, x, e, o);
-        __builtin_amdgcn_sched_barrier(0); /* keep the next chunk's 64 loads behind this chunk's MFMAs */
-        wide_chunks<K, NPAD, k0 + 64>(row0, n, xrow, q, e, o);
+        __builtin_amdgcn_sched_barrier(0);
+        wide_chunks<K, NPAD, k0 + 64>(row0, n, xrow, q, wn, e, o);
     }
 }
 
@@ -95,7 +101,10 @@ __device__ __forceinline__ f32x4 wide_dense(const float* __restrict__ wl, const 
      * in vector register pairs) and spills them */
     WideGlobalPtr base = (WideGlobalPtr)(wl + 64 * grp);
     asm volatile("" : "+s"(base));
-    wide_chunks<K, NPAD, 0>(base, (unsigned)quad_neuron_of_lane(q.lane), xrow, q, e, o);
+    const unsigned n = (unsigned)quad_neuron_of_lane(q.lane);
+    float wk[64];
+    wide_load_chunk<K, NPAD, 0>(base, n, wk);
+    wide_chunks<K, NPAD, 0>(base, n, xrow, q, wk, e, o);
     return e + o;
 }
 
@@ -119,6 +128,83 @@ __device__ __forceinline__ void wide_trunk(const float* __restrict__ w, const La
     wave_sync();
 #pragma unroll
     for (int g = 0; g < NG; ++g) store4(trunk_row + 64 * g + q.n0, elu4(acc[g]));
+    wave_sync();
+}
+
+/* ---- the weight stream: every dense unit (one output group of one layer) enters with the
+ * first 64 rows of its weights already requested (buffer A) and, before its last chunk's MFMAs,
+ * requests the first chunk of the unit that follows it in the simulation — across groups, layers,
+ * nets and simulations — so only matrix work and the L2 bandwidth remain, not one L2 latency per
+ * unit.  Fan-ins are <= 128 (two chunks). */
+__device__ __forceinline__ WideGlobalPtr wide_base(const float* __restrict__ p) {
+    WideGlobalPtr b = (WideGlobalPtr)p;
+    asm volatile("" : "+s"(b)); /* scalar, opaque: see wide_dense */
+    return b;
+}
+
+/* K > 64: A = this unit's chunk 0 on entry, the next unit's chunk 0 on exit (B is scratch).
+ * K <= 64: A = this unit's chunk 0 on entry, B = the next unit's chunk 0 on exit. */
+template <int K, int NPAD, int KN, int NPADN>
+__device__ __forceinline__ f32x4 wide_unit(WideGlobalPtr base, const float* __restrict__ bias4, const float* xrow,
+                                           const QuadLane& q, float (&A)[64], float (&B)[64], WideGlobalPtr next) {
+    static_assert(K <= 128 && KN <= 128, "two chunks at most");
+    const unsigned n = (unsigned)quad_neuron_of_lane(q.lane);
+    const float4 bv = *reinterpret_cast<const float4*>(bias4);
+    f32x4 e = f32x4{bv.x, bv.y, bv.z, bv.w}, o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    float x[16];
+    if constexpr (K > 64) {
+        wide_load_chunk<K, NPAD, 64>(base, n, B);
+        quad_load_x(xrow, q.grp, x);
+        wide_mfma16<K, 0, 0>(A, x, e, o);
+        wide_mfma16<K, 0, 1>(A, x, e, o);
+        wide_mfma16<K, 0, 2>(A, x, e, o);
+        wide_mfma16<K, 0, 3>(A, x, e, o);
+        __builtin_amdgcn_sched_barrier(0);
+        wide_load_chunk<KN, NPADN, 0>(next, n, A);
+        quad_load_x(xrow + 64, q.grp, x);
+        wide_mfma16<K, 64, 0>(B, x, e, o);
+        wide_mfma16<K, 64, 1>(B, x, e, o);
+        wide_mfma16<K, 64, 2>(B, x, e, o);
+        wide_mfma16<K, 64, 3>(B, x, e, o);
+    } else {
+        wide_load_chunk<KN, NPADN, 0>(next, n, B);
+        quad_load_x(xrow, q.grp, x);
+        wide_mfma16<K, 0, 0>(A, x, e, o);
+        wide_mfma16<K, 0, 1>(A, x, e, o);
+        wide_mfma16<K, 0, 2>(A, x, e, o);
+        wide_mfma16<K, 0, 3>(A, x, e, o);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    return e + o;
+}
+
+/* wide_trunk on the weight stream, two output groups (NPAD = 128): A holds group 0's first chunk on
+ * entry and the first chunk of `next` (a unit with fan-in KN, row stride NPADN) on exit */
+template <int K, int KN, int NPADN>
+__device__ __forceinline__ void wide_trunk_pf(const float* __restrict__ w, const Layer ly, const float* xrow,
+                                              int extra_row, float* trunk_row, const QuadLane& q,
+                                              float (&A)[64], float (&B)[64], WideGlobalPtr next) {
+    constexpr int NPAD = 128;
+    WideGlobalPtr b0 = wide_base(w + ly.w_off), b1 = b0 + 64;
+    const float* bias = w + ly.b_off + q.n0;
+    f32x4 acc[2];
+    if constexpr (K > 64) {
+        acc[0] = wide_unit<K, NPAD, K, NPAD>(b0, bias, xrow, q, A, B, b1);
+        acc[1] = wide_unit<K, NPAD, KN, NPADN>(b1, bias + 64, xrow, q, A, B, next);
+    } else {
+        acc[0] = wide_unit<K, NPAD, K, NPAD>(b0, bias, xrow, q, A, B, b1);
+        acc[1] = wide_unit<K, NPAD, KN, NPADN>(b1, bias + 64, xrow, q, B, A, next);
+    }
+    if (extra_row >= 0) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const float4 c = *reinterpret_cast<const float4*>(w + ly.w_off + (size_t)extra_row * NPAD + 64 * g + q.n0);
+            acc[g] = f32x4{acc[g][0] + c.x, acc[g][1] + c.y, acc[g][2] + c.z, acc[g][3] + c.w};
+        }
+    }
+    wave_sync();
+#pragma unroll
+    for (int g = 0; g < 2; ++g) store4(trunk_row + 64 * g + q.n0, elu4(acc[g]));
     wave_sync();
 }
 
@@ -219,19 +305,23 @@ __device__ __forceinline__ void wide_representation(const Model& m, const WideBu
 }
 
 /* Dynamics_function on the hidden state in the game's xin row + action: the new hidden state
- * replaces it (and goes to the global row hdst); returns the reward's support expectation */
+ * replaces it (and goes to the global row hdst); returns the reward's support expectation.
+ * Weight stream: A = d_in group 0 chunk 0 on entry, p_in group 0 chunk 0 on exit. */
 template <int SD, int H>
-__device__ __forceinline__ float wide_dynamics(const Model& m, const WideBufs& B, const QuadLane& q, int action,
-                                               float* hdst) {
-    constexpr int HP = (H + 63) / 64 * 64;
-    float* xrow = B.xin + q.c * kWideX;
-    float* trow = B.trunk + q.c * kWideTrunk;
-    wide_trunk<SD, HP>(m.w, m.d_in, xrow, SD + action, trow, q);
-    wide_mid<H>(m, m.d_mid, trow, q);
+__device__ __forceinline__ float wide_dynamics(const Model& m, const WideBufs& Bf, const QuadLane& q, int action,
+                                               float* hdst, float (&A)[64], float (&B)[64]) {
+    static_assert(H > 64 && H <= 128 && SD <= 64, "two trunk groups, one chunk of state inputs");
+    float* xrow = Bf.xin + q.c * kWideX;
+    float* trow = Bf.trunk + q.c * kWideTrunk;
+    WideGlobalPtr heads = wide_base(m.w + m.d_heads.w_off), mid = wide_base(m.w + m.d_mid.w_off);
+    wide_trunk_pf<SD, H, 128>(m.w, m.d_in, xrow, SD + action, trow, q, A, B, m.L > 0 ? mid : heads);
+    for (int l = 0; l < m.L; ++l)
+        wide_trunk_pf<H, H, 128>(m.w, m.d_mid, trow, -1, trow, q, A, B, l + 1 < m.L ? mid : heads);
     const WideValid vd = wide_valid(q, SD);
-    const f32x4 ar = wide_dense<H, 128>(m.w + m.d_heads.w_off, m.w + m.d_heads.b_off, 0, trow, q);
+    const float* hb = m.w + m.d_heads.b_off + q.n0;
+    const f32x4 ar = wide_unit<H, 128, H, 128>(heads, hb, trow, q, A, B, heads + 64);
     const float reward = wide_support_mean(wide_softmax(ar, vd), vd, q, SD);
-    const f32x4 as = wide_dense<H, 128>(m.w + m.d_heads.w_off, m.w + m.d_heads.b_off, 1, trow, q);
+    const f32x4 as = wide_unit<H, 128, SD, 128>(heads + 64, hb + 64, trow, q, A, B, wide_base(m.w + m.p_in.w_off));
     const f32x4 y = wide_scale_to_bound(as, vd);
     wave_sync();
     store4(xrow + q.n0, y);
@@ -241,20 +331,29 @@ __device__ __forceinline__ float wide_dynamics(const Model& m, const WideBufs& B
 }
 
 /* Prediction_function on the hidden state in the game's xin row: priors of actions 0..3 in the
- * lanes with n0 == 0; returns the value's support expectation */
+ * lanes with n0 == 0; returns the value's support expectation.  Weight stream: A = p_in group 0
+ * chunk 0 on entry, d_in group 0 chunk 0 (the next simulation's first unit) on exit. */
 template <int SD, int H>
-__device__ __forceinline__ float wide_prediction(const Model& m, const WideBufs& B, const QuadLane& q, int n_actions,
-                                                 f32x4* prior) {
-    constexpr int HP = (H + 63) / 64 * 64;
-    float* xrow = B.xin + q.c * kWideX;
-    float* trow = B.trunk + q.c * kWideTrunk;
-    wide_trunk<SD, HP>(m.w, m.p_in, xrow, -1, trow, q);
-    wide_mid<H>(m, m.p_mid, trow, q);
-    const f32x4 ap = wide_dense<H, 128>(m.w + m.p_heads.w_off, m.w + m.p_heads.b_off, 0, trow, q);
+__device__ __forceinline__ float wide_prediction(const Model& m, const WideBufs& Bf, const QuadLane& q, int n_actions,
+                                                 f32x4* prior, float (&A)[64], float (&B)[64]) {
+    float* xrow = Bf.xin + q.c * kWideX;
+    float* trow = Bf.trunk + q.c * kWideTrunk;
+    WideGlobalPtr heads = wide_base(m.w + m.p_heads.w_off), mid = wide_base(m.w + m.p_mid.w_off);
+    wide_trunk_pf<SD, H, 128>(m.w, m.p_in, xrow, -1, trow, q, A, B, m.L > 0 ? mid : heads);
+    for (int l = 0; l < m.L; ++l)
+        wide_trunk_pf<H, H, 128>(m.w, m.p_mid, trow, -1, trow, q, A, B, l + 1 < m.L ? mid : heads);
+    const float* hb = m.w + m.p_heads.b_off + q.n0;
+    const f32x4 ap = wide_unit<H, 128, H, 128>(heads, hb, trow, q, A, B, heads + 64);
     *prior = wide_softmax(ap, wide_valid(q, n_actions));
     const WideValid vd = wide_valid(q, SD);
-    const f32x4 av = wide_dense<H, 128>(m.w + m.p_heads.w_off, m.w + m.p_heads.b_off, 1, trow, q);
+    const f32x4 av = wide_unit<H, 128, SD, 128>(heads + 64, hb + 64, trow, q, A, B, wide_base(m.w + m.d_in.w_off));
     return wide_support_mean(wide_softmax(av, vd), vd, q, SD);
+}
+
+/* request the first chunk of the prediction net's first unit (before the root's prediction) */
+template <int SD, int H>
+__device__ __forceinline__ void wide_stream_start(const Model& m, const QuadLane& q, float (&A)[64]) {
+    wide_load_chunk<SD, 128, 0>(wide_base(m.w + m.p_in.w_off), (unsigned)quad_neuron_of_lane(q.lane), A);
 }
 
 }  // namespace mzs

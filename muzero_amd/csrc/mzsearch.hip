@@ -524,7 +524,9 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
     for (int k = q.b; k < kWideX; k += 16) xrow[k] = k < m.obs_dim ? p.obs[(size_t)g * m.obs_dim + k] : 0.0f;
     wave_sync();
     wide_representation<SD, H>(m, B, q, hid_g);
-    (void)wide_prediction<SD, H>(m, B, q, NA, &pr);
+    float wsa[64], wsb[64]; /* the weight stream's two chunk buffers (mzs_quadw.h) */
+    wide_stream_start<SD, H>(m, q, wsa);
+    (void)wide_prediction<SD, H>(m, B, q, NA, &pr, wsa, wsb);
     if (q.b == 0) {
 #pragma unroll
         for (int r = 0; r < NA; ++r) L.nodes[1 + r].prior = pr[r];
@@ -554,8 +556,8 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
         const float4 hv = *reinterpret_cast<const float4*>(hid_g + (size_t)e_parent * p.t.hid_stride + 4 * q.b);
         *reinterpret_cast<float4*>(xrow + 4 * q.b) = hv;
         wave_sync();
-        const float yr = wide_dynamics<SD, H>(m, B, q, sel.action, hid_g + (size_t)e_new * p.t.hid_stride);
-        const float yv = wide_prediction<SD, H>(m, B, q, NA, &pr);
+        const float yr = wide_dynamics<SD, H>(m, B, q, sel.action, hid_g + (size_t)e_new * p.t.hid_stride, wsa, wsb);
+        const float yv = wide_prediction<SD, H>(m, B, q, NA, &pr, wsa, wsb);
         float reward, value;
         halves_pair(quad_inverse_value_transform(q.half ? yv : yr), reward, value);
         const int cbase = 1 + e_new * NA;
