@@ -261,6 +261,135 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 #define DIAG_ADD(i, a, b)
 #endif
 
+/* ---- pieces shared by the four-games-per-wave kernels (k_search_quad, k_search_quadw) ---- */
+
+/* block-shared tables at the start of dynamic LDS: sqrt(n) pb_c(n), 1/n in f64 and f32
+ * (correctly rounded reciprocals for div_r*); the caller synchronises the block afterwards */
+__device__ __forceinline__ void quad_fill_tables(unsigned char* smem, const QuadLayout& ql, const SearchParams& p) {
+    double* pbc_s = reinterpret_cast<double*>(smem);
+    double* inv64_s = reinterpret_cast<double*>(smem + ql.off_inv64);
+    float* inv32_s = reinterpret_cast<float*>(smem + ql.off_inv32);
+    for (int i = threadIdx.x; i < p.S + 2; i += blockDim.x) {
+        pbc_s[i] = p.pbc[i];
+        inv64_s[i] = 1.0 / (double)(i > 0 ? i : 1);
+        inv32_s[i] = 1.0f / (float)(i > 0 ? i : 1);
+    }
+}
+
+/* this lane's view of the block's LDS: shared tables, its wave's buffers, its game's tree */
+__device__ __forceinline__ QuadLds quad_carve(unsigned char* smem, const QuadLayout& ql, int wave, const QuadLane& q,
+                                              bool with_hidden) {
+    unsigned char* wbase = smem + ql.shared_bytes + (size_t)wave * ql.wave_bytes;
+    unsigned char* gbase = wbase + ql.off_games + (size_t)q.c * ql.g_bytes;
+    QuadLds L;
+    L.trunk = reinterpret_cast<float*>(wbase);
+    L.nwin = reinterpret_cast<double*>(wbase + ql.off_nwin);
+    L.onehot = reinterpret_cast<const float*>(smem + ql.off_onehot);
+    L.pbc = reinterpret_cast<const double*>(smem);
+    L.inv64 = reinterpret_cast<const double*>(smem + ql.off_inv64);
+    L.inv32 = reinterpret_cast<const float*>(smem + ql.off_inv32);
+    L.nodes = reinterpret_cast<QNode*>(gbase);
+    L.vsum = reinterpret_cast<float*>(gbase + ql.g_vsum);
+    L.path = reinterpret_cast<uint2*>(gbase + ql.g_path);
+    L.hid = with_hidden ? reinterpret_cast<float*>(gbase + ql.g_hid) : nullptr;
+    L.leafs = reinterpret_cast<unsigned short*>(gbase + ql.g_leafs);
+    return L;
+}
+
+__device__ __forceinline__ QuadState quad_state_init() {
+    QuadState s;
+    s.mn = __builtin_inff();
+    s.mx = -__builtin_inff();
+    s.rinv = 0.0f;
+    s.rootp = 0.0;
+    s.consumed = 0;
+    s.path_total = 0;
+    s.status = 0;
+    return s;
+}
+
+/* empty tree: every node unvisited, the root (reward 0) on the path */
+__device__ __forceinline__ void quad_tree_init(const QuadLds& L, const QuadLane& q, int n_nodes) {
+    for (int n = q.b; n < n_nodes; n += 16) {
+        QNode z;
+        z.vc = 0u;
+        z.x0 = 0.0f;
+        z.prior = 0.0f;
+        z.reward = 0.0f;
+        L.nodes[n] = z;
+        L.vsum[n] = 0.0f;
+    }
+    if (q.b == 0) L.path[0] = make_uint2(0u, 0u);
+}
+
+/* expand the root with the priors pr (mcts.py:113-123) and mix the exploration noise into them
+ * (add_exploration_noise_at_the_root, mcts.py:134-145: f32 product widened, f64 sum) */
+template <int NA>
+__device__ __forceinline__ void quad_root_expand(const QuadLds& L, QuadState& s, const QuadLane& q,
+                                                 const SearchParams& p, int g, const f32x4 pr) {
+    if (q.b == 0) {
+#pragma unroll
+        for (int r = 0; r < NA; ++r) L.nodes[1 + r].prior = pr[r];
+        L.nodes[0].vc = 1u;
+    }
+    wave_sync();
+    constexpr int NAL = NA <= 2 ? 2 : 4;
+    const int a = q.b & (NAL - 1);
+    if (a < NA) {
+        const float pa = L.nodes[1 + a].prior;
+        if (p.train && p.S > 0)
+            s.rootp = (double)(pa * p.omf32) + p.dirichlet[(size_t)g * NA + a] * p.frac;
+        else
+            s.rootp = (double)pa;
+    }
+}
+
+/* expand the selected leaf (mcts.py:186-200) */
+template <int NA>
+__device__ __forceinline__ void quad_expand(const QuadLds& L, const QuadLane& q, const QuadSelect<NA>& sel, int sim,
+                                            const f32x4 pr, float reward) {
+    const int cbase = 1 + (sim + 1) * NA;
+    if (q.b == 0) {
+#pragma unroll
+        for (int r = 0; r < NA; ++r) L.nodes[cbase + r].prior = pr[r];
+        L.nodes[sel.leaf].reward = reward;
+        L.nodes[sel.leaf].vc = (unsigned)cbase; /* never visited before its expansion */
+        L.leafs[sim] = (unsigned short)sel.leaf;
+        L.path[sel.depth].y = __float_as_uint(reward);
+    }
+    wave_sync();
+}
+
+/* tree -> HBM structure of arrays; results (mcts.py:215-222).  Hidden states are the caller's. */
+template <int NA>
+__device__ __forceinline__ void quad_write_out(const SearchParams& p, const QuadLds& L, const QuadState& s,
+                                               const QuadLane& q, int g) {
+    const size_t row = (size_t)g * p.t.stride;
+    for (int n = q.b; n < p.n_nodes; n += 16) {
+        const QNode nd = L.nodes[n];
+        p.t.visit[row + n] = (int)(nd.vc >> 16);
+        p.t.vsum[row + n] = L.vsum[n];
+        p.t.prior[row + n] = nd.prior;
+        p.t.reward[row + n] = nd.reward;
+        p.t.child_base[row + n] = (int)(nd.vc & 0xffffu);
+    }
+    for (int i = q.b; i < p.S; i += 16) p.t.sim_leaf[(size_t)g * p.t.max_sims + i] = L.leafs[i];
+    constexpr int NAL = NA <= 2 ? 2 : 4;
+    if (q.b < NAL && q.b < NA) {
+        p.r.visits[(size_t)g * NA + q.b] = (int)(L.nodes[1 + q.b].vc >> 16);
+        p.r.root_prior[(size_t)g * NA + q.b] = s.rootp;
+    }
+    if (q.b == 0) {
+        const int rv = (int)(L.nodes[0].vc >> 16);
+        p.r.root_value[g] = rv == 0 ? 0.0f : L.vsum[0] / (float)rv;
+        p.r.consumed[g] = s.consumed;
+        p.r.path_len[g] = s.path_total;
+        p.t.minmax[2 * (size_t)g] = s.mn;
+        p.t.minmax[2 * (size_t)g + 1] = s.mx;
+        p.t.status[g] = s.status;
+    }
+}
+
 template <int SD, int NA, int H, bool kInjected, bool kMid = false>
 __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, const QuadLayout ql) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -269,18 +398,11 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
     const Model& m = p.m;
     const int S = p.S;
 
-    /* block-shared tables, then the only block-level barrier */
-    double* pbc_s = reinterpret_cast<double*>(smem);
-    double* inv64_s = reinterpret_cast<double*>(smem + ql.off_inv64);
-    float* inv32_s = reinterpret_cast<float*>(smem + ql.off_inv32);
-    float* onehot_s = reinterpret_cast<float*>(smem + ql.off_onehot);
-    for (int i = threadIdx.x; i < S + 2; i += blockDim.x) {
-        pbc_s[i] = p.pbc[i];
-        inv64_s[i] = 1.0 / (double)(i > 0 ? i : 1); /* correctly rounded reciprocals (div_r*) */
-        inv32_s[i] = 1.0f / (float)(i > 0 ? i : 1);
-    }
+    /* block-shared tables, register-resident weights, then the only block-level barrier */
+    quad_fill_tables(smem, ql, p);
     QuadWeights<SD, NA, H, kMid> W;
     if (!kInjected) {
+        float* onehot_s = reinterpret_cast<float*>(smem + ql.off_onehot);
         for (int i = threadIdx.x; i < NA * 64; i += blockDim.x)
             onehot_s[i] = m.w[m.d_in.w_off + (SD + (i >> 6)) * 64 + (i & 63)];
         quad_load_weights<SD, NA, H, kMid>(m, W, q);
@@ -291,44 +413,13 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
     if (g0 >= p.n_games) return;
     const bool live = g0 + q.c < p.n_games;          /* dead slots replay the last game, write nothing */
     const int g = live ? g0 + q.c : p.n_games - 1;
-
-    unsigned char* wbase = smem + ql.shared_bytes + (size_t)wave * ql.wave_bytes;
-    unsigned char* gbase = wbase + ql.off_games + (size_t)q.c * ql.g_bytes;
-    QuadLds L;
-    L.trunk = reinterpret_cast<float*>(wbase);
-    L.nwin = reinterpret_cast<double*>(wbase + ql.off_nwin);
-    L.onehot = onehot_s;
-    L.pbc = pbc_s;
-    L.inv64 = inv64_s;
-    L.inv32 = inv32_s;
-    L.nodes = reinterpret_cast<QNode*>(gbase);
-    L.vsum = reinterpret_cast<float*>(gbase + ql.g_vsum);
-    L.path = reinterpret_cast<uint2*>(gbase + ql.g_path);
-    L.hid = reinterpret_cast<float*>(gbase + ql.g_hid);
-    L.leafs = reinterpret_cast<unsigned short*>(gbase + ql.g_leafs);
+    const QuadLds L = quad_carve(smem, ql, wave, q, true);
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
     const int noise_cap = p.noise ? (int)p.noise_stride : 0;
 
-    QuadState s;
-    s.mn = __builtin_inff();
-    s.mx = -__builtin_inff();
-    s.rinv = 0.0f;
-    s.rootp = 0.0;
-    s.consumed = 0;
-    s.path_total = 0;
-    s.status = 0;
-
-    for (int n = q.b; n < p.n_nodes; n += 16) {
-        QNode z;
-        z.vc = 0u;
-        z.x0 = 0.0f;
-        z.prior = 0.0f;
-        z.reward = 0.0f;
-        L.nodes[n] = z;
-        L.vsum[n] = 0.0f;
-    }
-    if (q.b == 0) L.path[0] = make_uint2(0u, 0u); /* the root: reward 0 */
+    QuadState s = quad_state_init();
+    quad_tree_init(L, q, p.n_nodes);
     double nz = S > 0 ? quad_noise_prefetch<NA>(s, q, noise, noise_cap) : 0.0;
 
     /* root: representation -> prediction -> expand (mcts.py:88-123) */
@@ -342,24 +433,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
         quad_representation<SD, NA, H>(m, L, q, L.hid);
         (void)quad_prediction<SD, NA, H, kMid>(W, L, q, L.hid, &pr, m.L);   /* the root's value is not used */
     }
-    if (q.b == 0) {
-#pragma unroll
-        for (int r = 0; r < NA; ++r) L.nodes[1 + r].prior = pr[r];
-        L.nodes[0].vc = 1u;
-    }
-    wave_sync();
-    {
-        /* add_exploration_noise_at_the_root (mcts.py:134-145): f32 product widened, f64 sum */
-        constexpr int NAL = NA <= 2 ? 2 : 4;
-        const int a = q.b & (NAL - 1);
-        if (a < NA) {
-            const float pa = L.nodes[1 + a].prior;
-            if (p.train && S > 0)
-                s.rootp = (double)(pa * p.omf32) + p.dirichlet[(size_t)g * NA + a] * p.frac;
-            else
-                s.rootp = (double)pa;
-        }
-    }
+    quad_root_expand<NA>(L, s, q, p, g, pr);
 
 #ifdef MZS_DIAG
     unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -390,17 +464,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
             halves_pair(quad_inverse_value_transform(q.half ? yv : yr), reward, value);
         }
         DIAG_T(t3);
-        /* expand (mcts.py:186-200) */
-        const int cbase = 1 + e_new * NA;
-        if (q.b == 0) {
-#pragma unroll
-            for (int r = 0; r < NA; ++r) L.nodes[cbase + r].prior = pr[r];
-            L.nodes[sel.leaf].reward = reward;
-            L.nodes[sel.leaf].vc = (unsigned)cbase; /* never visited before its expansion */
-            L.leafs[sim] = (unsigned short)sel.leaf;
-            L.path[sel.depth].y = __float_as_uint(reward);
-        }
-        wave_sync();
+        quad_expand<NA>(L, q, sel, sim, pr, reward);
         quad_backup(L, s, q, sel.depth, value, p.g32);
         DIAG_T(t4);
         DIAG_ADD(1, t0, t1);
@@ -408,38 +472,14 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
         DIAG_ADD(4, t3, t4);
     }
 
-    /* tree + hidden states -> HBM structure of arrays; results (mcts.py:215-222) */
     if (live) {
-        const size_t row = (size_t)g * p.t.stride;
-        for (int n = q.b; n < p.n_nodes; n += 16) {
-            const QNode nd = L.nodes[n];
-            p.t.visit[row + n] = (int)(nd.vc >> 16);
-            p.t.vsum[row + n] = L.vsum[n];
-            p.t.prior[row + n] = nd.prior;
-            p.t.reward[row + n] = nd.reward;
-            p.t.child_base[row + n] = (int)(nd.vc & 0xffffu);
-        }
-        for (int i = q.b; i < S; i += 16) p.t.sim_leaf[(size_t)g * p.t.max_sims + i] = L.leafs[i];
-        if (!kInjected) {
+        quad_write_out<NA>(p, L, s, q, g);
+        if (!kInjected) { /* hidden states of the expansions */
             float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * p.t.hid_stride;
             for (int i = q.b; i < (S + 1) * 32; i += 16) {
                 const int e = i >> 5, k = i & 31;
                 if (k < SD) hid_g[(size_t)e * p.t.hid_stride + k] = L.hid[i];
             }
-        }
-        constexpr int NAL = NA <= 2 ? 2 : 4;
-        if (q.b < NAL && q.b < NA) {
-            p.r.visits[(size_t)g * NA + q.b] = (int)(L.nodes[1 + q.b].vc >> 16);
-            p.r.root_prior[(size_t)g * NA + q.b] = s.rootp;
-        }
-        if (q.b == 0) {
-            const int rv = (int)(L.nodes[0].vc >> 16);
-            p.r.root_value[g] = rv == 0 ? 0.0f : L.vsum[0] / (float)rv;
-            p.r.consumed[g] = s.consumed;
-            p.r.path_len[g] = s.path_total;
-            p.t.minmax[2 * (size_t)g] = s.mn;
-            p.t.minmax[2 * (size_t)g + 1] = s.mx;
-            p.t.status[g] = s.status;
         }
     }
 #ifdef MZS_DIAG
@@ -460,63 +500,25 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
     const Model& m = p.m;
     const int S = p.S;
 
-    double* pbc_s = reinterpret_cast<double*>(smem);
-    double* inv64_s = reinterpret_cast<double*>(smem + ql.off_inv64);
-    float* inv32_s = reinterpret_cast<float*>(smem + ql.off_inv32);
-    for (int i = threadIdx.x; i < S + 2; i += blockDim.x) {
-        pbc_s[i] = p.pbc[i];
-        inv64_s[i] = 1.0 / (double)(i > 0 ? i : 1);
-        inv32_s[i] = 1.0f / (float)(i > 0 ? i : 1);
-    }
+    quad_fill_tables(smem, ql, p);
     __syncthreads();
 
     const int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 4;
     if (g0 >= p.n_games) return;
     const bool live = g0 + q.c < p.n_games;
     const int g = live ? g0 + q.c : p.n_games - 1;
-
-    unsigned char* wbase = smem + ql.shared_bytes + (size_t)wave * ql.wave_bytes;
-    unsigned char* gbase = wbase + ql.off_games + (size_t)q.c * ql.g_bytes;
+    const QuadLds L = quad_carve(smem, ql, wave, q, false);
     WideBufs B;
-    B.trunk = reinterpret_cast<float*>(wbase);
-    B.xin = reinterpret_cast<float*>(wbase + 4 * kWideTrunk * 4);
-    QuadLds L;
-    L.trunk = B.trunk;
-    L.nwin = reinterpret_cast<double*>(wbase + ql.off_nwin);
-    L.onehot = nullptr;
-    L.pbc = pbc_s;
-    L.inv64 = inv64_s;
-    L.inv32 = inv32_s;
-    L.nodes = reinterpret_cast<QNode*>(gbase);
-    L.vsum = reinterpret_cast<float*>(gbase + ql.g_vsum);
-    L.path = reinterpret_cast<uint2*>(gbase + ql.g_path);
-    L.hid = nullptr;
-    L.leafs = reinterpret_cast<unsigned short*>(gbase + ql.g_leafs);
+    B.trunk = L.trunk;
+    B.xin = L.trunk + 4 * kWideTrunk;
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
     const int noise_cap = p.noise ? (int)p.noise_stride : 0;
     float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * p.t.hid_stride;
     float* xrow = B.xin + q.c * kWideX;
 
-    QuadState s;
-    s.mn = __builtin_inff();
-    s.mx = -__builtin_inff();
-    s.rinv = 0.0f;
-    s.rootp = 0.0;
-    s.consumed = 0;
-    s.path_total = 0;
-    s.status = 0;
-
-    for (int n = q.b; n < p.n_nodes; n += 16) {
-        QNode z;
-        z.vc = 0u;
-        z.x0 = 0.0f;
-        z.prior = 0.0f;
-        z.reward = 0.0f;
-        L.nodes[n] = z;
-        L.vsum[n] = 0.0f;
-    }
-    if (q.b == 0) L.path[0] = make_uint2(0u, 0u);
+    QuadState s = quad_state_init();
+    quad_tree_init(L, q, p.n_nodes);
     double nz = S > 0 ? quad_noise_prefetch<NA>(s, q, noise, noise_cap) : 0.0;
 
     /* root: representation -> prediction -> expand (mcts.py:88-123) */
@@ -527,32 +529,15 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
     float wsa[64], wsb[64]; /* the weight stream's two chunk buffers (mzs_quadw.h) */
     wide_stream_start<SD, H>(m, q, wsa);
     (void)wide_prediction<SD, H>(m, B, q, NA, &pr, wsa, wsb);
-    if (q.b == 0) {
-#pragma unroll
-        for (int r = 0; r < NA; ++r) L.nodes[1 + r].prior = pr[r];
-        L.nodes[0].vc = 1u;
-    }
-    wave_sync();
-    {
-        constexpr int NAL = NA <= 2 ? 2 : 4;
-        const int a = q.b & (NAL - 1);
-        if (a < NA) {
-            const float pa = L.nodes[1 + a].prior;
-            if (p.train && S > 0)
-                s.rootp = (double)(pa * p.omf32) + p.dirichlet[(size_t)g * NA + a] * p.frac;
-            else
-                s.rootp = (double)pa;
-        }
-    }
+    quad_root_expand<NA>(L, s, q, p, g, pr);
 
     for (int sim = 0; sim < S; ++sim) {
         L.nwin[q.lane] = nz;
         wave_sync();
         const QuadSelect<NA> sel = quad_select<NA>(L, s, q, noise, noise_cap, sim);
         nz = quad_noise_prefetch<NA>(s, q, noise, noise_cap);
-        const int e_new = sim + 1;
         /* the parent's hidden state: 64 floats per game, four per lane */
-        const int e_parent = (sel.pbase - 1) / NA;
+        const int e_new = sim + 1, e_parent = (sel.pbase - 1) / NA;
         const float4 hv = *reinterpret_cast<const float4*>(hid_g + (size_t)e_parent * p.t.hid_stride + 4 * q.b);
         *reinterpret_cast<float4*>(xrow + 4 * q.b) = hv;
         wave_sync();
@@ -560,45 +545,10 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
         const float yv = wide_prediction<SD, H>(m, B, q, NA, &pr, wsa, wsb);
         float reward, value;
         halves_pair(quad_inverse_value_transform(q.half ? yv : yr), reward, value);
-        const int cbase = 1 + e_new * NA;
-        if (q.b == 0) {
-#pragma unroll
-            for (int r = 0; r < NA; ++r) L.nodes[cbase + r].prior = pr[r];
-            L.nodes[sel.leaf].reward = reward;
-            L.nodes[sel.leaf].vc = (unsigned)cbase;
-            L.leafs[sim] = (unsigned short)sel.leaf;
-            L.path[sel.depth].y = __float_as_uint(reward);
-        }
-        wave_sync();
+        quad_expand<NA>(L, q, sel, sim, pr, reward);
         quad_backup(L, s, q, sel.depth, value, p.g32);
     }
-
-    if (live) {
-        const size_t row = (size_t)g * p.t.stride;
-        for (int n = q.b; n < p.n_nodes; n += 16) {
-            const QNode nd = L.nodes[n];
-            p.t.visit[row + n] = (int)(nd.vc >> 16);
-            p.t.vsum[row + n] = L.vsum[n];
-            p.t.prior[row + n] = nd.prior;
-            p.t.reward[row + n] = nd.reward;
-            p.t.child_base[row + n] = (int)(nd.vc & 0xffffu);
-        }
-        for (int i = q.b; i < S; i += 16) p.t.sim_leaf[(size_t)g * p.t.max_sims + i] = L.leafs[i];
-        constexpr int NAL = NA <= 2 ? 2 : 4;
-        if (q.b < NAL && q.b < NA) {
-            p.r.visits[(size_t)g * NA + q.b] = (int)(L.nodes[1 + q.b].vc >> 16);
-            p.r.root_prior[(size_t)g * NA + q.b] = s.rootp;
-        }
-        if (q.b == 0) {
-            const int rv = (int)(L.nodes[0].vc >> 16);
-            p.r.root_value[g] = rv == 0 ? 0.0f : L.vsum[0] / (float)rv;
-            p.r.consumed[g] = s.consumed;
-            p.r.path_len[g] = s.path_total;
-            p.t.minmax[2 * (size_t)g] = s.mn;
-            p.t.minmax[2 * (size_t)g + 1] = s.mx;
-            p.t.status[g] = s.status;
-        }
-    }
+    if (live) quad_write_out<NA>(p, L, s, q, g);
 }
 
 /* ------------------------------------------------------------------------------
