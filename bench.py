@@ -47,6 +47,8 @@ def search_kernel_name(obs_dim, A, S_dim, H, L, kind):
     mid = "true" if L > 0 else "false"
     if kind == 0 and obs_dim <= 64 and (S_dim, A, H) == (61, 2, 128):
         return "k_search_quadw<61,2,128>"
+    if kind == 1 and obs_dim <= 64 and (S_dim, A, H, L) == (31, 2, 64, 1):
+        return "k_search_quadl<31,2,64>"
     return f"k_search_quad<{S_dim},{A},{H},false,{mid}>" if quad else "k_search_fused<false>"
 
 

@@ -1,0 +1,126 @@
+/*
+ * mzs_quadl.h — the 'lstm_model' (neural_network_lstm_model.py) on the four-games-per-wavefront
+ * search: lane roles, tree code and arithmetic of mzs_quad.h, weights streamed from the device
+ * store as in mzs_quadw.h (the four heads do not share trunks, so a simulation touches 892 weight
+ * rows: more than the register file holds).
+ *
+ * One head = Linear (K inputs -> H) and one LSTM layer stepped from zero state: the i, g, o gate
+ * projections are three 64-neuron output groups of one fused layer (columns 0, 64, 128 of
+ * LstmHead::gate[0]); a lane holds the same four units of each gate, so the cell step
+ * h = sigmoid(o) * tanh(sigmoid(i) * tanh(g)) is lane-local.  Every unit of the weight stream is a
+ * single chunk (fan-in <= 64): it consumes one buffer and requests the next unit's rows into the
+ * other, so the buffers swap roles from unit to unit (four units per head: the roles are back
+ * where they started after each head).
+ * Compile-time S_dim (<= 32... 64), H (<= 64) and A; one LSTM layer (number_of_hidden_layer = 1).
+ *
+ * Reference code restated (file:line in /root/reference): neural_network_lstm_model.py:10-80,
+ * muzero_model.py:828-905 (as mzs_device.h lstm_head / model_*).
+ */
+#ifndef MZS_QUADL_H
+#define MZS_QUADL_H
+
+#include "mzs_quadw.h"
+
+namespace mzs {
+
+/* one head on the input row xrow (LDS, KIN values): h of the LSTM layer, units n0..n0+3 of this
+ * lane's game.  Weight stream: X = the head's Linear chunk on entry, the first chunk of `next` (a
+ * Linear with fan-in KN, row stride 64) on exit; Y is scratch.  trow: the game's 64-float row for
+ * the Linear's output (the B operand of the gates). */
+template <int KIN, int H, int KN>
+__device__ __forceinline__ f32x4 lstm_head_quad(const Model& m, const LstmHead& hd, const float* xrow, int extra_row,
+                                                float* trow, const QuadLane& q, float (&X)[64], float (&Y)[64],
+                                                WideGlobalPtr next) {
+    static_assert(H <= 64 && KIN <= 64, "single-chunk units");
+    const float* __restrict__ w = m.w;
+    WideGlobalPtr gates = wide_base(w + hd.gate[0].w_off);
+    f32x4 lin = wide_unit<KIN, 64, H, 192>(wide_base(w + hd.lin.w_off), w + hd.lin.b_off + q.n0, xrow, q, X, Y, gates);
+    if (extra_row >= 0) { /* one-hot action column of the dynamics heads */
+        const float4 c = *reinterpret_cast<const float4*>(w + hd.lin.w_off + (size_t)extra_row * 64 + q.n0);
+        lin = f32x4{lin[0] + c.x, lin[1] + c.y, lin[2] + c.z, lin[3] + c.w};
+    }
+    wave_sync();
+    store4(trow + q.n0, lin);
+    wave_sync();
+    const float* gb = w + hd.gate[0].b_off + q.n0; /* bias_ih, then bias_hh after the chain */
+    const float* hb = w + hd.bhh_off[0] + q.n0;
+    const f32x4 gi = wide_unit<H, 192, H, 192>(gates, gb, trow, q, Y, X, gates + 64);
+    const f32x4 gg = wide_unit<H, 192, H, 192>(gates + 64, gb + 64, trow, q, X, Y, gates + 128);
+    const f32x4 go = wide_unit<H, 192, KN, 64>(gates + 128, gb + 128, trow, q, Y, X, next);
+    const float4 bi = *reinterpret_cast<const float4*>(hb), bg = *reinterpret_cast<const float4*>(hb + 64),
+                 bo = *reinterpret_cast<const float4*>(hb + 128);
+    return f32x4{mzs_lstm_cell0(gi[0] + bi.x, gg[0] + bg.x, go[0] + bo.x),
+                 mzs_lstm_cell0(gi[1] + bi.y, gg[1] + bg.y, go[1] + bo.y),
+                 mzs_lstm_cell0(gi[2] + bi.z, gg[2] + bg.z, go[2] + bo.z),
+                 mzs_lstm_cell0(gi[3] + bi.w, gg[3] + bg.w, go[3] + bo.w)};
+}
+
+/* Representation_function: one Linear, no activation (lstm:19-21); observation in the game's xin
+ * row -> hidden state there and in the global row hdst.  Root only: runtime fan-in. */
+template <int SD>
+__device__ __forceinline__ void lstm_representation_quad(const Model& m, const WideBufs& Bf, const QuadLane& q,
+                                                         float* hdst, int hid_stride) {
+    float* xrow = Bf.xin + q.c * kWideX;
+    const int n = quad_neuron_of_lane(q.lane);
+    const float4 bv = *reinterpret_cast<const float4*>(m.w + m.r_in.b_off + q.n0);
+    f32x4 e = f32x4{bv.x, bv.y, bv.z, bv.w}, o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+    for (int k = 0; k < m.obs_dim; ++k) {
+        const float wk = m.w[m.r_in.w_off + (size_t)k * 64 + n], xk = xrow[k];
+        if (k & 1)
+            o = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, xk, o, 0, 0, 0);
+        else
+            e = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, xk, e, 0, 0, 0);
+    }
+    f32x4 y = e + o;
+    const WideValid vd = wide_valid(q, SD);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = vd.v[r] ? y[r] : 0.0f;
+    wave_sync();
+    store4(xrow + q.n0, y);
+    if (q.n0 < hid_stride) store4(hdst + q.n0, y);
+    wave_sync();
+}
+
+/* Dynamics_function: reward head then next-state head (its raw LSTM output is the new hidden
+ * state, lstm:49-51).  Stream: X = reward Linear chunk on entry, policy Linear chunk on exit. */
+template <int SD, int H>
+__device__ __forceinline__ float lstm_dynamics_quad(const Model& m, const WideBufs& Bf, const QuadLane& q, int action,
+                                                    float* hdst, int hid_stride, float (&X)[64], float (&Y)[64]) {
+    float* xrow = Bf.xin + q.c * kWideX;
+    float* trow = Bf.trunk + q.c * kWideTrunk;
+    const WideValid vd = wide_valid(q, SD);
+    const f32x4 hr = lstm_head_quad<SD, H, SD>(m, m.l_rew, xrow, SD + action, trow, q, X, Y,
+                                               wide_base(m.w + m.l_st.lin.w_off));
+    const float reward = wide_support_mean(wide_softmax(hr, vd), vd, q, SD);
+    f32x4 hs = lstm_head_quad<SD, H, SD>(m, m.l_st, xrow, SD + action, trow, q, X, Y,
+                                         wide_base(m.w + m.l_pol.lin.w_off));
+#pragma unroll
+    for (int r = 0; r < 4; ++r) hs[r] = vd.v[r] ? hs[r] : 0.0f;
+    wave_sync();
+    store4(xrow + q.n0, hs);
+    if (q.n0 < hid_stride) store4(hdst + q.n0, hs);
+    wave_sync();
+    return reward;
+}
+
+/* Prediction_function: policy head, value head.  Stream: X = policy Linear chunk on entry, reward
+ * Linear chunk (the next simulation's first unit) on exit. */
+template <int SD, int H>
+__device__ __forceinline__ float lstm_prediction_quad(const Model& m, const WideBufs& Bf, const QuadLane& q,
+                                                      int n_actions, f32x4* prior, float (&X)[64], float (&Y)[64]) {
+    float* xrow = Bf.xin + q.c * kWideX;
+    float* trow = Bf.trunk + q.c * kWideTrunk;
+    const f32x4 hp = lstm_head_quad<SD, H, SD>(m, m.l_pol, xrow, -1, trow, q, X, Y, wide_base(m.w + m.l_val.lin.w_off));
+    *prior = wide_softmax(hp, wide_valid(q, n_actions));
+    const f32x4 hv = lstm_head_quad<SD, H, SD>(m, m.l_val, xrow, -1, trow, q, X, Y, wide_base(m.w + m.l_rew.lin.w_off));
+    const WideValid vd = wide_valid(q, SD);
+    return wide_support_mean(wide_softmax(hv, vd), vd, q, SD);
+}
+
+template <int SD>
+__device__ __forceinline__ void lstm_stream_start(const Model& m, const QuadLane& q, float (&X)[64]) {
+    wide_load_chunk<SD, 64, 0>(wide_base(m.w + m.l_pol.lin.w_off), (unsigned)quad_neuron_of_lane(q.lane), X);
+}
+
+}  // namespace mzs
+#endif

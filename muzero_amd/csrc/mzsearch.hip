@@ -19,6 +19,7 @@
 #include "mzs_device.h"
 #include "mzs_quad.h"
 #include "mzs_quadw.h"
+#include "mzs_quadl.h"
 #include "mzs_train.h"
 #include "mzs_selfplay.h"
 #include "mzs_replay.h"
@@ -552,6 +553,68 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
 }
 
 /* ------------------------------------------------------------------------------
+ * k_search_quadl: four games per wave for the 'lstm_model' (mzs_quadl.h): the structure of
+ * k_search_quadw with the LSTM heads.
+ * ---------------------------------------------------------------------------- */
+template <int SD, int NA, int H>
+__global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, const QuadLayout ql) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const QuadLane q = quad_lane();
+    const int wave = threadIdx.x >> 6;
+    const Model& m = p.m;
+    const int S = p.S, hs = p.t.hid_stride;
+
+    quad_fill_tables(smem, ql, p);
+    __syncthreads();
+
+    const int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 4;
+    if (g0 >= p.n_games) return;
+    const bool live = g0 + q.c < p.n_games;
+    const int g = live ? g0 + q.c : p.n_games - 1;
+    const QuadLds L = quad_carve(smem, ql, wave, q, false);
+    WideBufs B;
+    B.trunk = L.trunk;
+    B.xin = L.trunk + 4 * kWideTrunk;
+
+    const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
+    const int noise_cap = p.noise ? (int)p.noise_stride : 0;
+    float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * hs;
+    float* xrow = B.xin + q.c * kWideX;
+
+    QuadState s = quad_state_init();
+    quad_tree_init(L, q, p.n_nodes);
+    double nz = S > 0 ? quad_noise_prefetch<NA>(s, q, noise, noise_cap) : 0.0;
+
+    f32x4 pr;
+    for (int k = q.b; k < kWideX; k += 16) xrow[k] = k < m.obs_dim ? p.obs[(size_t)g * m.obs_dim + k] : 0.0f;
+    wave_sync();
+    lstm_representation_quad<SD>(m, B, q, hid_g, hs);
+    float wsa[64], wsb[64]; /* the weight stream's two chunk buffers */
+    lstm_stream_start<SD>(m, q, wsa);
+    (void)lstm_prediction_quad<SD, H>(m, B, q, NA, &pr, wsa, wsb);
+    quad_root_expand<NA>(L, s, q, p, g, pr);
+
+    for (int sim = 0; sim < S; ++sim) {
+        L.nwin[q.lane] = nz;
+        wave_sync();
+        const QuadSelect<NA> sel = quad_select<NA>(L, s, q, noise, noise_cap, sim);
+        nz = quad_noise_prefetch<NA>(s, q, noise, noise_cap);
+        const int e_new = sim + 1, e_parent = (sel.pbase - 1) / NA;
+        float4 hv = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (4 * q.b < hs) hv = *reinterpret_cast<const float4*>(hid_g + (size_t)e_parent * hs + 4 * q.b);
+        *reinterpret_cast<float4*>(xrow + 4 * q.b) = hv;
+        wave_sync();
+        const float yr = lstm_dynamics_quad<SD, H>(m, B, q, sel.action, hid_g + (size_t)e_new * hs, hs, wsa, wsb);
+        const float yv = lstm_prediction_quad<SD, H>(m, B, q, NA, &pr, wsa, wsb);
+        float reward, value;
+        halves_pair(quad_inverse_value_transform(q.half ? yv : yr), reward, value);
+        quad_expand<NA>(L, q, sel, sim, pr, reward);
+        quad_backup(L, s, q, sel.depth, value, p.g32);
+    }
+    if (live) quad_write_out<NA>(p, L, s, q, g);
+}
+
+/* ------------------------------------------------------------------------------
  * Standalone batched inference (wave per sample): the Muzero.*_inference wrappers
  * (muzero_model.py:828-905).
  * ---------------------------------------------------------------------------- */
@@ -991,6 +1054,13 @@ quad_kernel_t pick_quadw_kernel(const mzs_dims& d) {
     return nullptr;
 }
 
+/* 'lstm_model' on the weight stream (mzs_quadl.h): one LSTM layer, the shape of the LSTM fixture */
+quad_kernel_t pick_quadl_kernel(const mzs_dims& d) {
+    if (d.model_kind != MZS_MODEL_LSTM || d.n_mid_layers != 1 || d.obs_dim > 64) return nullptr;
+    if (d.state_dim == 31 && d.hidden_dim == 64 && d.n_actions == 2) return k_search_quadl<31, 2, 64>;
+    return nullptr;
+}
+
 quad_kernel_t pick_quad_injected(int A) {
     if (A == 2) return k_search_quad<31, 2, 64, true>;
     if (A == 3) return k_search_quad<31, 3, 64, true>;
@@ -1228,7 +1298,9 @@ int mzs_search(mzs_handle* h, int32_t n_games, int32_t S, int32_t train, const f
             const int wpb = quad_waves_per_block(ql);
             if (wpb > 0) return launch_quad(qk, p, ql, wpb, static_cast<hipStream_t>(stream));
         }
-        if (quad_kernel_t qk = pick_quadw_kernel(h->cfg.dims)) {
+        quad_kernel_t wide = pick_quadw_kernel(h->cfg.dims);
+        if (!wide) wide = pick_quadl_kernel(h->cfg.dims);
+        if (quad_kernel_t qk = wide) {
             const QuadLayout ql = make_quadw_layout(p.n_nodes, S);
             const int wpb = quad_waves_per_block(ql);
             if (wpb > 0) return launch_quad(qk, p, ql, wpb, static_cast<hipStream_t>(stream));

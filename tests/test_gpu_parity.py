@@ -248,12 +248,15 @@ def test_saturated_logits_bit_exact(shape):
         eng.close()
 
 
-def test_full_size_4096_games_vs_oracle():
-    """BASELINE config C2: 4096 games x 50 simulations, tag-123 weights, against the
-    oracle on all games (bit-exact), plus size-independent invariants."""
+@pytest.mark.parametrize("tag", ["tag123", "tag133", "tag127", "lstmA"])
+def test_full_size_4096_games_vs_oracle(tag):
+    """BASELINE config C2: 4096 games x 50 simulations against the oracle on all games (bit-exact),
+    plus size-independent invariants — tag-123 weights (the benchmark: k_search_quad), and the same
+    size on the tied-mid-layer variant (tag 133), the wide kernel (tag 127: k_search_quadw) and the
+    LSTM model (generic kernel)."""
     from muzero_amd import rng
     from oracle import mz_oracle as mzo
-    d, blob = fixture_weights("tag123")
+    d, blob = fixture_weights(tag)
     G, S, A = 4096, 50, 2
     obs = np.random.RandomState(1000).uniform(-0.05, 0.05, size=(G, 4)).astype(np.float32)
     dirichlet, noise = rng.noise_streams(np.arange(G), A, S, 0.25, True)
@@ -269,8 +272,6 @@ def test_full_size_4096_games_vs_oracle():
     assert np.all(out["consumed"] == A * out["path_len"])
     # each expanded node's visit count = 1 + sum of its children's
     cb, vis = tree["child_base"], tree["visit"]
-    for a in range(A):
-        pass
     exp = cb > 0
     child_sum = np.zeros_like(vis)
     gi, ni = np.nonzero(exp)
