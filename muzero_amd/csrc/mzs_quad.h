@@ -199,6 +199,7 @@ struct QuadLds {
 
 struct QuadLayout {
     int off_inv64, off_inv32, off_onehot, shared_bytes; /* block-shared part: pbc at 0  */
+    int off_tabs;                                       /* small-vector tables (mzs_quadw.h WideTabs), else 0 */
     int off_nwin, off_games, wave_bytes;                /* per wave: trunk at 0         */
     int g_vsum, g_path, g_hid, g_leafs, g_bytes;        /* per game: nodes at 0         */
 };

@@ -23,6 +23,8 @@
 #ifndef MZS_QUADW_H
 #define MZS_QUADW_H
 
+#include <utility>
+
 #include "mzs_quad.h"
 
 namespace mzs {
@@ -68,6 +70,70 @@ __device__ __forceinline__ void wide_load_chunk(WideGlobalPtr row0, unsigned n, 
         if (k0 + j < K) wk[j] = rk[n];
     }
 }
+
+/* ---- where a chunk of weight rows comes from ----------------------------------------------
+ * DirectStream: from the device weight store (W^T [k][n_pad]), one 256-byte row per
+ * global_load_dword: 64 vector-memory instructions per chunk.  Their issue, not the cache
+ * bandwidth, is what such a kernel waits for (measured: ~1100 stall cycles per chunk next to 560
+ * cycles of matrix work; TCP traffic at half the L1's rate).
+ * ImageStream: from the chunk images of k_build_stream — the weights of one simulation in
+ * consumption order, 16 KB per chunk in the layout [k / 4][neuron][4]: a lane fetches four
+ * consecutive k of its neuron with one global_load_dwordx4 and the wave's 64 lanes cover one
+ * contiguous KiB: 16 instructions per chunk.  (Tried and dropped: one copy per block in an LDS ring
+ * filled by LDS-DMA — bit-exact with compiler-visible reads, but four global_load_lds per wave
+ * and step plus the barrier cost what the shared copy saves: DESIGN.md 4.) */
+constexpr int kImageFloats = 64 * 64;
+constexpr int kMaxImages = 48;
+
+/* where the small per-unit vectors of the simulation loop live: the store, or the block's LDS
+ * copy made at kernel start (image kernels) */
+struct WideTabs {
+    const float *d_in_b, *d_mid_b, *d_heads_b, *p_in_b, *p_mid_b, *p_heads_b; /* biases [128] */
+    const float* d_onehot;                                                    /* [A][128]: the action rows of d_in */
+};
+constexpr int kWideTabFloats = 6 * 128; /* + A * 128 */
+
+struct DirectStream {
+    /* request the chunk that follows the one about to be multiplied */
+    template <int K, int NPAD, int k0>
+    __device__ __forceinline__ void begin(WideGlobalPtr row0, unsigned n, float (&wk)[64]) {
+        wide_load_chunk<K, NPAD, k0>(row0, n, wk);
+    }
+};
+
+struct ImageStream {
+    WideGlobalPtr img; /* image 0 + this lane's neuron */
+    int n_img, next_img;
+    __device__ __forceinline__ void init(const float* images, int n_images, int lane) {
+        img = (WideGlobalPtr)images + 4 * quad_neuron_of_lane(lane);
+        n_img = n_images;
+        next_img = 0;
+    }
+    template <int KV>
+    __device__ __forceinline__ void load(float (&wk)[64]) {
+        typedef const __attribute__((address_space(1))) f32x4* P4;
+        P4 b = (P4)(img + (size_t)next_img * kImageFloats);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            if (4 * j < KV) {
+                const f32x4 v = b[j * 64];
+                wk[4 * j] = v[0], wk[4 * j + 1] = v[1], wk[4 * j + 2] = v[2], wk[4 * j + 3] = v[3];
+            }
+        }
+        next_img = next_img + 1 == n_img ? 0 : next_img + 1;
+    }
+    /* the first chunk (image `first`, KV rows used) */
+    template <int KV>
+    __device__ __forceinline__ void start(int first, float (&wk)[64]) {
+        next_img = first;
+        load<KV>(wk);
+    }
+    template <int K, int NPAD, int k0>
+    __device__ __forceinline__ void begin(WideGlobalPtr, unsigned, float (&wk)[64]) {
+        load<(K - k0 < 64 ? K - k0 : 64)>(wk);
+    }
+};
+
 
 /* chunk k0 (its weight rows already requested into wk) and the chunks after it: the next chunk's
  * 64 rows are requested before this chunk's MFMAs, so their latency overlaps 512 cycles of matrix
@@ -142,37 +208,37 @@ __device__ __forceinline__ WideGlobalPtr wide_base(const float* __restrict__ p) 
     return b;
 }
 
+/* the matrix work of one chunk: rows k0 .. k0+63 of a layer with fan-in K, in cur */
+template <int K, int k0>
+__device__ __forceinline__ void wide_block(const float (&cur)[64], const float (&x)[16], f32x4& e, f32x4& o) {
+    wide_mfma16<K, k0, 0>(cur, x, e, o);
+    wide_mfma16<K, k0, 1>(cur, x, e, o);
+    wide_mfma16<K, k0, 2>(cur, x, e, o);
+    wide_mfma16<K, k0, 3>(cur, x, e, o);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 /* K > 64: A = this unit's chunk 0 on entry, the next unit's chunk 0 on exit (B is scratch).
  * K <= 64: A = this unit's chunk 0 on entry, B = the next unit's chunk 0 on exit. */
-template <int K, int NPAD, int KN, int NPADN>
-__device__ __forceinline__ f32x4 wide_unit(WideGlobalPtr base, const float* __restrict__ bias4, const float* xrow,
+template <int K, int NPAD, int KN, int NPADN, class St>
+__device__ __forceinline__ f32x4 wide_unit(St& st, WideGlobalPtr base, const float* __restrict__ bias4, const float* xrow,
                                            const QuadLane& q, float (&A)[64], float (&B)[64], WideGlobalPtr next) {
     static_assert(K <= 128 && KN <= 128, "two chunks at most");
     const unsigned n = (unsigned)quad_neuron_of_lane(q.lane);
     const float4 bv = *reinterpret_cast<const float4*>(bias4);
     f32x4 e = f32x4{bv.x, bv.y, bv.z, bv.w}, o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     float x[16];
+    quad_load_x(xrow, q.grp, x);
     if constexpr (K > 64) {
-        wide_load_chunk<K, NPAD, 64>(base, n, B);
-        quad_load_x(xrow, q.grp, x);
-        wide_mfma16<K, 0, 0>(A, x, e, o);
-        wide_mfma16<K, 0, 1>(A, x, e, o);
-        wide_mfma16<K, 0, 2>(A, x, e, o);
-        wide_mfma16<K, 0, 3>(A, x, e, o);
-        __builtin_amdgcn_sched_barrier(0);
-        wide_load_chunk<KN, NPADN, 0>(next, n, A);
-        quad_load_x(xrow + 64, q.grp, x);
-        wide_mfma16<K, 64, 0>(B, x, e, o);
-        wide_mfma16<K, 64, 1>(B, x, e, o);
-        wide_mfma16<K, 64, 2>(B, x, e, o);
-        wide_mfma16<K, 64, 3>(B, x, e, o);
+        float x2[16];
+        quad_load_x(xrow + 64, q.grp, x2);
+        st.template begin<K, NPAD, 64>(base, n, B);
+        wide_block<K, 0>(A, x, e, o);
+        st.template begin<KN, NPADN, 0>(next, n, A);
+        wide_block<K, 64>(B, x2, e, o);
     } else {
-        wide_load_chunk<KN, NPADN, 0>(next, n, B);
-        quad_load_x(xrow, q.grp, x);
-        wide_mfma16<K, 0, 0>(A, x, e, o);
-        wide_mfma16<K, 0, 1>(A, x, e, o);
-        wide_mfma16<K, 0, 2>(A, x, e, o);
-        wide_mfma16<K, 0, 3>(A, x, e, o);
+        st.template begin<KN, NPADN, 0>(next, n, B);
+        wide_block<K, 0>(A, x, e, o);
     }
     __builtin_amdgcn_sched_barrier(0);
     return e + o;
@@ -180,27 +246,30 @@ __device__ __forceinline__ f32x4 wide_unit(WideGlobalPtr base, const float* __re
 
 /* wide_trunk on the weight stream, two output groups (NPAD = 128): A holds group 0's first chunk on
  * entry and the first chunk of `next` (a unit with fan-in KN, row stride NPADN) on exit */
-template <int K, int KN, int NPADN>
-__device__ __forceinline__ void wide_trunk_pf(const float* __restrict__ w, const Layer ly, const float* xrow,
-                                              int extra_row, float* trunk_row, const QuadLane& q,
-                                              float (&A)[64], float (&B)[64], WideGlobalPtr next) {
+template <int K, int KN, int NPADN, class St>
+__device__ __forceinline__ void wide_trunk_pf(St& st, const float* __restrict__ wl, const float* bias_row,
+                                              const float* extra, const float* xrow, float* trunk_row,
+                                              const QuadLane& q, float (&A)[64], float (&B)[64], WideGlobalPtr next) {
     constexpr int NPAD = 128;
-    WideGlobalPtr b0 = wide_base(w + ly.w_off), b1 = b0 + 64;
-    const float* bias = w + ly.b_off + q.n0;
+    WideGlobalPtr b0 = wide_base(wl), b1 = b0 + 64;
+    const float* bias = bias_row + q.n0;
     f32x4 acc[2];
-    if constexpr (K > 64) {
-        acc[0] = wide_unit<K, NPAD, K, NPAD>(b0, bias, xrow, q, A, B, b1);
-        acc[1] = wide_unit<K, NPAD, KN, NPADN>(b1, bias + 64, xrow, q, A, B, next);
-    } else {
-        acc[0] = wide_unit<K, NPAD, K, NPAD>(b0, bias, xrow, q, A, B, b1);
-        acc[1] = wide_unit<K, NPAD, KN, NPADN>(b1, bias + 64, xrow, q, B, A, next);
+    float4 c[2];
+    if (extra) { /* the one-hot action row (wave-uniform presence, per-game row): read before the units */
+        c[0] = *reinterpret_cast<const float4*>(extra + q.n0);
+        c[1] = *reinterpret_cast<const float4*>(extra + 64 + q.n0);
     }
-    if (extra_row >= 0) {
+    if constexpr (K > 64) {
+        acc[0] = wide_unit<K, NPAD, K, NPAD>(st, b0, bias, xrow, q, A, B, b1);
+        acc[1] = wide_unit<K, NPAD, KN, NPADN>(st, b1, bias + 64, xrow, q, A, B, next);
+    } else {
+        acc[0] = wide_unit<K, NPAD, K, NPAD>(st, b0, bias, xrow, q, A, B, b1);
+        acc[1] = wide_unit<K, NPAD, KN, NPADN>(st, b1, bias + 64, xrow, q, B, A, next);
+    }
+    if (extra) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const float4 c = *reinterpret_cast<const float4*>(w + ly.w_off + (size_t)extra_row * NPAD + 64 * g + q.n0);
-            acc[g] = f32x4{acc[g][0] + c.x, acc[g][1] + c.y, acc[g][2] + c.z, acc[g][3] + c.w};
-        }
+        for (int g = 0; g < 2; ++g)
+            acc[g] = f32x4{acc[g][0] + c[g].x, acc[g][1] + c[g].y, acc[g][2] + c[g].z, acc[g][3] + c[g].w};
     }
     wave_sync();
 #pragma unroll
@@ -307,21 +376,24 @@ __device__ __forceinline__ void wide_representation(const Model& m, const WideBu
 /* Dynamics_function on the hidden state in the game's xin row + action: the new hidden state
  * replaces it (and goes to the global row hdst); returns the reward's support expectation.
  * Weight stream: A = d_in group 0 chunk 0 on entry, p_in group 0 chunk 0 on exit. */
-template <int SD, int H>
-__device__ __forceinline__ float wide_dynamics(const Model& m, const WideBufs& Bf, const QuadLane& q, int action,
-                                               float* hdst, float (&A)[64], float (&B)[64]) {
+template <int SD, int H, class St>
+__device__ __forceinline__ float wide_dynamics(St& st, const Model& m, const WideTabs& T, const WideBufs& Bf,
+                                               const QuadLane& q, int action, float* hdst, float (&A)[64],
+                                               float (&B)[64]) {
     static_assert(H > 64 && H <= 128 && SD <= 64, "two trunk groups, one chunk of state inputs");
     float* xrow = Bf.xin + q.c * kWideX;
     float* trow = Bf.trunk + q.c * kWideTrunk;
     WideGlobalPtr heads = wide_base(m.w + m.d_heads.w_off), mid = wide_base(m.w + m.d_mid.w_off);
-    wide_trunk_pf<SD, H, 128>(m.w, m.d_in, xrow, SD + action, trow, q, A, B, m.L > 0 ? mid : heads);
+    wide_trunk_pf<SD, H, 128>(st, m.w + m.d_in.w_off, T.d_in_b, T.d_onehot + action * 128, xrow, trow, q, A, B,
+                              m.L > 0 ? mid : heads);
     for (int l = 0; l < m.L; ++l)
-        wide_trunk_pf<H, H, 128>(m.w, m.d_mid, trow, -1, trow, q, A, B, l + 1 < m.L ? mid : heads);
+        wide_trunk_pf<H, H, 128>(st, m.w + m.d_mid.w_off, T.d_mid_b, nullptr, trow, trow, q, A, B,
+                                 l + 1 < m.L ? mid : heads);
     const WideValid vd = wide_valid(q, SD);
-    const float* hb = m.w + m.d_heads.b_off + q.n0;
-    const f32x4 ar = wide_unit<H, 128, H, 128>(heads, hb, trow, q, A, B, heads + 64);
+    const float* hb = T.d_heads_b + q.n0;
+    const f32x4 ar = wide_unit<H, 128, H, 128>(st, heads, hb, trow, q, A, B, heads + 64);
     const float reward = wide_support_mean(wide_softmax(ar, vd), vd, q, SD);
-    const f32x4 as = wide_unit<H, 128, SD, 128>(heads + 64, hb + 64, trow, q, A, B, wide_base(m.w + m.p_in.w_off));
+    const f32x4 as = wide_unit<H, 128, SD, 128>(st, heads + 64, hb + 64, trow, q, A, B, wide_base(m.w + m.p_in.w_off));
     const f32x4 y = wide_scale_to_bound(as, vd);
     wave_sync();
     store4(xrow + q.n0, y);
@@ -333,27 +405,33 @@ __device__ __forceinline__ float wide_dynamics(const Model& m, const WideBufs& B
 /* Prediction_function on the hidden state in the game's xin row: priors of actions 0..3 in the
  * lanes with n0 == 0; returns the value's support expectation.  Weight stream: A = p_in group 0
  * chunk 0 on entry, d_in group 0 chunk 0 (the next simulation's first unit) on exit. */
-template <int SD, int H>
-__device__ __forceinline__ float wide_prediction(const Model& m, const WideBufs& Bf, const QuadLane& q, int n_actions,
-                                                 f32x4* prior, float (&A)[64], float (&B)[64]) {
+template <int SD, int H, class St>
+__device__ __forceinline__ float wide_prediction(St& st, const Model& m, const WideTabs& T, const WideBufs& Bf,
+                                                 const QuadLane& q, int n_actions, f32x4* prior, float (&A)[64],
+                                                 float (&B)[64]) {
     float* xrow = Bf.xin + q.c * kWideX;
     float* trow = Bf.trunk + q.c * kWideTrunk;
     WideGlobalPtr heads = wide_base(m.w + m.p_heads.w_off), mid = wide_base(m.w + m.p_mid.w_off);
-    wide_trunk_pf<SD, H, 128>(m.w, m.p_in, xrow, -1, trow, q, A, B, m.L > 0 ? mid : heads);
+    wide_trunk_pf<SD, H, 128>(st, m.w + m.p_in.w_off, T.p_in_b, nullptr, xrow, trow, q, A, B, m.L > 0 ? mid : heads);
     for (int l = 0; l < m.L; ++l)
-        wide_trunk_pf<H, H, 128>(m.w, m.p_mid, trow, -1, trow, q, A, B, l + 1 < m.L ? mid : heads);
-    const float* hb = m.w + m.p_heads.b_off + q.n0;
-    const f32x4 ap = wide_unit<H, 128, H, 128>(heads, hb, trow, q, A, B, heads + 64);
+        wide_trunk_pf<H, H, 128>(st, m.w + m.p_mid.w_off, T.p_mid_b, nullptr, trow, trow, q, A, B,
+                                 l + 1 < m.L ? mid : heads);
+    const float* hb = T.p_heads_b + q.n0;
+    const f32x4 ap = wide_unit<H, 128, H, 128>(st, heads, hb, trow, q, A, B, heads + 64);
     *prior = wide_softmax(ap, wide_valid(q, n_actions));
     const WideValid vd = wide_valid(q, SD);
-    const f32x4 av = wide_unit<H, 128, SD, 128>(heads + 64, hb + 64, trow, q, A, B, wide_base(m.w + m.d_in.w_off));
+    const f32x4 av = wide_unit<H, 128, SD, 128>(st, heads + 64, hb + 64, trow, q, A, B, wide_base(m.w + m.d_in.w_off));
     return wide_support_mean(wide_softmax(av, vd), vd, q, SD);
 }
 
-/* request the first chunk of the prediction net's first unit (before the root's prediction) */
-template <int SD, int H>
-__device__ __forceinline__ void wide_stream_start(const Model& m, const QuadLane& q, float (&A)[64]) {
-    wide_load_chunk<SD, 128, 0>(wide_base(m.w + m.p_in.w_off), (unsigned)quad_neuron_of_lane(q.lane), A);
+/* request the first chunk of the prediction net's first unit (before the root's prediction);
+ * image stream: image `first_img` (the prediction net's first unit in the stream's order) */
+template <int SD, int H, class St>
+__device__ __forceinline__ void wide_stream_start(St& st, const Model& m, const QuadLane& q, int first_img, float (&A)[64]) {
+    if constexpr (std::is_same<St, ImageStream>::value)
+        st.template start<SD>(first_img, A);
+    else
+        wide_load_chunk<SD, 128, 0>(wide_base(m.w + m.p_in.w_off), (unsigned)quad_neuron_of_lane(q.lane), A);
 }
 
 }  // namespace mzs

@@ -13,6 +13,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/mzsearch.h"
@@ -89,6 +90,8 @@ struct SearchParams {
     const float* t_reward;
     const float* t_value;
     const float* t_prior;
+    const float* img; /* chunk images of one simulation in consumption order (k_build_stream) */
+    int n_img, first_img;
 };
 
 __device__ __forceinline__ WaveLds carve(unsigned char* base, const LdsLayout& l) {
@@ -489,11 +492,19 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
 #endif
 }
 
+/* block-cooperative copy of n floats of the weight store into LDS (before the block's barrier) */
+__device__ __forceinline__ const float* tab_copy(float*& cursor, const float* src, int n) {
+    float* dst = cursor;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) dst[i] = src[i];
+    cursor += n;
+    return dst;
+}
+
 /* ------------------------------------------------------------------------------
  * k_search_quadw: four games per wave for wide MLPs (mzs_quadw.h): weights streamed from the
  * store, hidden states in the global SoA array, trees in LDS.  Same search code as k_search_quad.
  * ---------------------------------------------------------------------------- */
-template <int SD, int NA, int H>
+template <int SD, int NA, int H, bool kImages>
 __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, const QuadLayout ql) {
     extern __shared__ __align__(16) unsigned char smem[];
     const QuadLane q = quad_lane();
@@ -502,6 +513,24 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
     const int S = p.S;
 
     quad_fill_tables(smem, ql, p);
+    WideTabs T;
+    {
+        const float* w = m.w;
+        if constexpr (kImages) {
+            float* cur = reinterpret_cast<float*>(smem + ql.off_tabs);
+            T.d_in_b = tab_copy(cur, w + m.d_in.b_off, 128);
+            T.d_mid_b = tab_copy(cur, w + m.d_mid.b_off, 128);
+            T.d_heads_b = tab_copy(cur, w + m.d_heads.b_off, 128);
+            T.p_in_b = tab_copy(cur, w + m.p_in.b_off, 128);
+            T.p_mid_b = tab_copy(cur, w + m.p_mid.b_off, 128);
+            T.p_heads_b = tab_copy(cur, w + m.p_heads.b_off, 128);
+            T.d_onehot = tab_copy(cur, w + m.d_in.w_off + SD * 128, NA * 128);
+        } else {
+            T.d_in_b = w + m.d_in.b_off, T.d_mid_b = w + m.d_mid.b_off, T.d_heads_b = w + m.d_heads.b_off;
+            T.p_in_b = w + m.p_in.b_off, T.p_mid_b = w + m.p_mid.b_off, T.p_heads_b = w + m.p_heads.b_off;
+            T.d_onehot = w + m.d_in.w_off + SD * 128;
+        }
+    }
     __syncthreads();
 
     const int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 4;
@@ -512,6 +541,8 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
     WideBufs B;
     B.trunk = L.trunk;
     B.xin = L.trunk + 4 * kWideTrunk;
+    typename std::conditional<kImages, ImageStream, DirectStream>::type st;
+    if constexpr (kImages) st.init(p.img, p.n_img, q.lane);
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
     const int noise_cap = p.noise ? (int)p.noise_stride : 0;
@@ -528,11 +559,15 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
     wave_sync();
     wide_representation<SD, H>(m, B, q, hid_g);
     float wsa[64], wsb[64]; /* the weight stream's two chunk buffers (mzs_quadw.h) */
-    wide_stream_start<SD, H>(m, q, wsa);
-    (void)wide_prediction<SD, H>(m, B, q, NA, &pr, wsa, wsb);
+    wide_stream_start<SD, H>(st, m, q, p.first_img, wsa);
+    (void)wide_prediction<SD, H>(st, m, T, B, q, NA, &pr, wsa, wsb);
     quad_root_expand<NA>(L, s, q, p, g, pr);
 
+#ifdef MZS_DIAG
+    unsigned long long dsum[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     for (int sim = 0; sim < S; ++sim) {
+        DIAG_T(t0);
         L.nwin[q.lane] = nz;
         wave_sync();
         const QuadSelect<NA> sel = quad_select<NA>(L, s, q, noise, noise_cap, sim);
@@ -542,13 +577,26 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
         const float4 hv = *reinterpret_cast<const float4*>(hid_g + (size_t)e_parent * p.t.hid_stride + 4 * q.b);
         *reinterpret_cast<float4*>(xrow + 4 * q.b) = hv;
         wave_sync();
-        const float yr = wide_dynamics<SD, H>(m, B, q, sel.action, hid_g + (size_t)e_new * p.t.hid_stride, wsa, wsb);
-        const float yv = wide_prediction<SD, H>(m, B, q, NA, &pr, wsa, wsb);
+        DIAG_T(t1);
+        const float yr = wide_dynamics<SD, H>(st, m, T, B, q, sel.action, hid_g + (size_t)e_new * p.t.hid_stride, wsa, wsb);
+        DIAG_T(t2);
+        const float yv = wide_prediction<SD, H>(st, m, T, B, q, NA, &pr, wsa, wsb);
+        DIAG_T(t3);
         float reward, value;
         halves_pair(quad_inverse_value_transform(q.half ? yv : yr), reward, value);
         quad_expand<NA>(L, q, sel, sim, pr, reward);
         quad_backup(L, s, q, sel.depth, value, p.g32);
+        DIAG_T(t4);
+        DIAG_ADD(1, t0, t1);
+        DIAG_ADD(2, t1, t2);
+        DIAG_ADD(3, t2, t3);
+        DIAG_ADD(4, t3, t4);
     }
+#ifdef MZS_DIAG
+
+    if (q.lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&g_diag[i], dsum[i]);
+#endif
     if (live) quad_write_out<NA>(p, L, s, q, g);
 }
 
@@ -556,7 +604,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
  * k_search_quadl: four games per wave for the 'lstm_model' (mzs_quadl.h): the structure of
  * k_search_quadw with the LSTM heads.
  * ---------------------------------------------------------------------------- */
-template <int SD, int NA, int H>
+template <int SD, int NA, int H, bool kImages>
 __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, const QuadLayout ql) {
     extern __shared__ __align__(16) unsigned char smem[];
     const QuadLane q = quad_lane();
@@ -565,6 +613,25 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
     const int S = p.S, hs = p.t.hid_stride;
 
     quad_fill_tables(smem, ql, p);
+    LstmTabs T;
+    {
+        const float* w = m.w;
+        float* cur = reinterpret_cast<float*>(smem + ql.off_tabs);
+        const auto head = [&](const LstmHead& hd, bool acts) {
+            LstmHeadTabs t;
+            if constexpr (kImages) {
+                t.lin_b = tab_copy(cur, w + hd.lin.b_off, 64);
+                t.gate_b = tab_copy(cur, w + hd.gate[0].b_off, 192);
+                t.bhh = tab_copy(cur, w + hd.bhh_off[0], 192);
+                t.extra = acts ? tab_copy(cur, w + hd.lin.w_off + SD * 64, NA * 64) : nullptr;
+            } else {
+                t.lin_b = w + hd.lin.b_off, t.gate_b = w + hd.gate[0].b_off, t.bhh = w + hd.bhh_off[0];
+                t.extra = acts ? w + hd.lin.w_off + SD * 64 : nullptr;
+            }
+            return t;
+        };
+        T.rew = head(m.l_rew, true), T.st = head(m.l_st, true), T.pol = head(m.l_pol, false), T.val = head(m.l_val, false);
+    }
     __syncthreads();
 
     const int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 4;
@@ -575,6 +642,8 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
     WideBufs B;
     B.trunk = L.trunk;
     B.xin = L.trunk + 4 * kWideTrunk;
+    typename std::conditional<kImages, ImageStream, DirectStream>::type st;
+    if constexpr (kImages) st.init(p.img, p.n_img, q.lane);
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
     const int noise_cap = p.noise ? (int)p.noise_stride : 0;
@@ -590,8 +659,8 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
     wave_sync();
     lstm_representation_quad<SD>(m, B, q, hid_g, hs);
     float wsa[64], wsb[64]; /* the weight stream's two chunk buffers */
-    lstm_stream_start<SD>(m, q, wsa);
-    (void)lstm_prediction_quad<SD, H>(m, B, q, NA, &pr, wsa, wsb);
+    lstm_stream_start<SD>(st, m, q, p.first_img, wsa);
+    (void)lstm_prediction_quad<SD, H>(st, m, T, B, q, NA, &pr, wsa, wsb);
     quad_root_expand<NA>(L, s, q, p, g, pr);
 
     for (int sim = 0; sim < S; ++sim) {
@@ -604,14 +673,40 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
         if (4 * q.b < hs) hv = *reinterpret_cast<const float4*>(hid_g + (size_t)e_parent * hs + 4 * q.b);
         *reinterpret_cast<float4*>(xrow + 4 * q.b) = hv;
         wave_sync();
-        const float yr = lstm_dynamics_quad<SD, H>(m, B, q, sel.action, hid_g + (size_t)e_new * hs, hs, wsa, wsb);
-        const float yv = lstm_prediction_quad<SD, H>(m, B, q, NA, &pr, wsa, wsb);
+        const float yr = lstm_dynamics_quad<SD, H>(st, m, T, B, q, sel.action, hid_g + (size_t)e_new * hs, hs, wsa, wsb);
+        const float yv = lstm_prediction_quad<SD, H>(st, m, T, B, q, NA, &pr, wsa, wsb);
         float reward, value;
         halves_pair(quad_inverse_value_transform(q.half ? yv : yr), reward, value);
         quad_expand<NA>(L, q, sel, sim, pr, reward);
         quad_backup(L, s, q, sel.depth, value, p.g32);
     }
     if (live) quad_write_out<NA>(p, L, s, q, g);
+}
+
+/* ------------------------------------------------------------------------------
+ * k_build_stream: the chunk images k_search_quadw / k_search_quadl consume (mzs_quadw.h
+ * ImageStream), from the device weight store: image u = rows k0 .. k0+63 of one 64-neuron output
+ * group in the layout [k / 4][neuron][4]; rows past the fan-in are zero (and never multiplied).
+ * One block per image, before every such search: the store changes under training, 0.3 MB of
+ * images cost less than tracking that.
+ * ---------------------------------------------------------------------------- */
+struct StreamUnit {
+    int w_off, npad, K, k0; /* W^T (+ the group's column) in the store, its row stride, fan-in, first row */
+};
+struct StreamPlan {
+    int n, first; /* images per simulation; the one the root's prediction starts at */
+    StreamUnit u[kMaxImages];
+};
+
+__global__ void __launch_bounds__(256) k_build_stream(const float* __restrict__ w, const StreamPlan plan,
+                                                      float* __restrict__ img) {
+    const StreamUnit u = plan.u[blockIdx.x];
+    float* out = img + (size_t)blockIdx.x * kImageFloats;
+    for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+        const int k = i >> 6, n = i & 63;
+        const float v = u.k0 + k < u.K ? w[u.w_off + (size_t)(u.k0 + k) * u.npad + n] : 0.0f;
+        out[((k >> 2) * 64 + n) * 4 + (k & 3)] = v;
+    }
 }
 
 /* ------------------------------------------------------------------------------
@@ -807,6 +902,8 @@ struct mzs_handle {
     float* blob_dev = nullptr;     /* master weights in blob order (include/mzs_layout.h)      */
     int* store_index_dev = nullptr; /* blob element -> offset in the device weight store        */
     double* pbc_dev = nullptr;
+    float* stream_dev = nullptr;   /* chunk images (k_build_stream) of the models that have a quadw / quadl kernel */
+    StreamPlan stream_plan;
     /* training (mzs_train_*): allocated by mzs_train_create */
     int train_batch = 0, train_K = 0, train_step = 0;
     TapeLayout tape_layout;
@@ -989,6 +1086,7 @@ QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model) {
     l.off_inv64 = round_up((S + 2) * 8, 16);
     l.off_inv32 = 2 * l.off_inv64;
     l.off_onehot = l.off_inv32 + round_up((S + 2) * 4, 16);
+    l.off_tabs = 0;
     l.shared_bytes = l.off_onehot + (with_model ? A * 64 * 4 : 0);
     l.off_nwin = 4 * 64 * 4;
     l.off_games = l.off_nwin + 64 * 8;
@@ -1008,12 +1106,13 @@ QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model) {
 
 /* LDS plan of k_search_quadw: trunk [4][128] and xin [4][64] per wave, trees per game, no hidden
  * states (they live in the global SoA array) */
-QuadLayout make_quadw_layout(int n_nodes, int S) {
+QuadLayout make_quadw_layout(int n_nodes, int S, int tab_floats) {
     QuadLayout l;
     l.off_inv64 = round_up((S + 2) * 8, 16);
     l.off_inv32 = 2 * l.off_inv64;
     l.off_onehot = l.off_inv32 + round_up((S + 2) * 4, 16);
-    l.shared_bytes = l.off_onehot;
+    l.off_tabs = l.off_onehot;
+    l.shared_bytes = l.off_tabs + round_up(tab_floats * 4, 16);
     l.off_nwin = 4 * kWideTrunk * 4 + 4 * kWideX * 4;
     l.off_games = l.off_nwin + 64 * 8;
     int off = n_nodes * (int)sizeof(QNode);
@@ -1047,18 +1146,54 @@ quad_kernel_t pick_quad_kernel(const mzs_dims& d) {
     return nullptr;
 }
 
-/* wide MLPs (mzs_quadw.h): the shape of experiments 127 / 128 */
-quad_kernel_t pick_quadw_kernel(const mzs_dims& d) {
+/* wide MLPs (mzs_quadw.h): the shape of experiments 127 / 128.  images: weights from the chunk
+ * images (ImageStream), else from the store (DirectStream: models with more than kMaxImages chunks) */
+quad_kernel_t pick_quadw_kernel(const mzs_dims& d, bool images) {
     if (d.model_kind != MZS_MODEL_MLP || d.obs_dim > 64) return nullptr;
-    if (d.state_dim == 61 && d.hidden_dim == 128 && d.n_actions == 2) return k_search_quadw<61, 2, 128>;
+    if (d.state_dim == 61 && d.hidden_dim == 128 && d.n_actions == 2)
+        return images ? k_search_quadw<61, 2, 128, true> : k_search_quadw<61, 2, 128, false>;
     return nullptr;
 }
 
 /* 'lstm_model' on the weight stream (mzs_quadl.h): one LSTM layer, the shape of the LSTM fixture */
-quad_kernel_t pick_quadl_kernel(const mzs_dims& d) {
+quad_kernel_t pick_quadl_kernel(const mzs_dims& d, bool images) {
     if (d.model_kind != MZS_MODEL_LSTM || d.n_mid_layers != 1 || d.obs_dim > 64) return nullptr;
-    if (d.state_dim == 31 && d.hidden_dim == 64 && d.n_actions == 2) return k_search_quadl<31, 2, 64>;
+    if (d.state_dim == 31 && d.hidden_dim == 64 && d.n_actions == 2)
+        return images ? k_search_quadl<31, 2, 64, true> : k_search_quadl<31, 2, 64, false>;
     return nullptr;
+}
+
+/* the chunk images of one simulation in the order the kernels consume them (n = 0: the model has
+ * no such kernel, or more images than kMaxImages) */
+StreamPlan make_stream_plan(const mzs_dims& d, const Model& m) {
+    StreamPlan pl;
+    pl.n = pl.first = 0;
+    std::vector<StreamUnit> v;
+    const auto unit = [&](const Layer& ly, int col, int K) {
+        for (int k0 = 0; k0 < K; k0 += 64) v.push_back(StreamUnit{ly.w_off + col, ly.n_pad, K, k0});
+    };
+    if (pick_quadw_kernel(d, true)) {
+        const auto net = [&](const Layer& in, const Layer& mid, const Layer& heads) {
+            unit(in, 0, m.Sd), unit(in, 64, m.Sd);
+            for (int l = 0; l < m.L; ++l) unit(mid, 0, m.H), unit(mid, 64, m.H);
+            unit(heads, 0, m.H), unit(heads, 64, m.H);
+        };
+        net(m.d_in, m.d_mid, m.d_heads);
+        pl.first = (int)v.size();
+        net(m.p_in, m.p_mid, m.p_heads);
+    } else if (pick_quadl_kernel(d, true)) {
+        const auto head = [&](const LstmHead& hd) {
+            unit(hd.lin, 0, m.Sd);
+            unit(hd.gate[0], 0, m.H), unit(hd.gate[0], 64, m.H), unit(hd.gate[0], 128, m.H);
+        };
+        head(m.l_rew), head(m.l_st);
+        pl.first = (int)v.size();
+        head(m.l_pol), head(m.l_val);
+    }
+    if (v.empty() || (int)v.size() > kMaxImages) return pl;
+    pl.n = (int)v.size();
+    for (int i = 0; i < pl.n; ++i) pl.u[i] = v[i];
+    return pl;
 }
 
 quad_kernel_t pick_quad_injected(int A) {
@@ -1218,6 +1353,12 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
         }
     }
     h->model.w = h->w_dev;
+    h->stream_plan = make_stream_plan(d, h->model);
+    if (h->stream_plan.n > 0 &&
+        (rc = dev_alloc(h, &h->stream_dev, (size_t)h->stream_plan.n * kImageFloats))) {
+        mzs_destroy(h);
+        return rc;
+    }
     *out = h;
     return MZS_OK;
 }
@@ -1298,12 +1439,27 @@ int mzs_search(mzs_handle* h, int32_t n_games, int32_t S, int32_t train, const f
             const int wpb = quad_waves_per_block(ql);
             if (wpb > 0) return launch_quad(qk, p, ql, wpb, static_cast<hipStream_t>(stream));
         }
-        quad_kernel_t wide = pick_quadw_kernel(h->cfg.dims);
-        if (!wide) wide = pick_quadl_kernel(h->cfg.dims);
+        const bool images = h->stream_plan.n > 0;
+        quad_kernel_t wide = pick_quadw_kernel(h->cfg.dims, images);
+        if (!wide) wide = pick_quadl_kernel(h->cfg.dims, images);
         if (quad_kernel_t qk = wide) {
-            const QuadLayout ql = make_quadw_layout(p.n_nodes, S);
+            const int A = h->cfg.dims.n_actions;
+            const int tab_floats = !images ? 0
+                                   : h->cfg.dims.model_kind == MZS_MODEL_LSTM ? 4 * kLstmHeadTabFloats + 2 * A * 64
+                                                                              : kWideTabFloats + A * 128;
+            const QuadLayout ql = make_quadw_layout(p.n_nodes, S, tab_floats);
             const int wpb = quad_waves_per_block(ql);
-            if (wpb > 0) return launch_quad(qk, p, ql, wpb, static_cast<hipStream_t>(stream));
+            if (wpb > 0) {
+                if (images) {
+                    hipLaunchKernelGGL(k_build_stream, dim3(h->stream_plan.n), dim3(256), 0,
+                                       static_cast<hipStream_t>(stream), h->w_dev, h->stream_plan, h->stream_dev);
+                    HIP_TRY(hipGetLastError());
+                    p.img = h->stream_dev;
+                    p.n_img = h->stream_plan.n;
+                    p.first_img = h->stream_plan.first;
+                }
+                return launch_quad(qk, p, ql, wpb, static_cast<hipStream_t>(stream));
+            }
         }
     }
     return launch(k_search_fused<false>, p, n_games, p.lds, static_cast<hipStream_t>(stream));

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""Diagnostic (not a benchmark): per-phase share of wave cycles in k_search_quad,
+"""Diagnostic (not a benchmark): per-phase share of wave cycles in k_search_quad / k_search_quadw,
 from a -DMZS_DIAG build of the library (s_memtime stamps).  Usage on the GPU box:
-MZS_LIB=$PWD/muzero_amd/libmzsearch_diag.so python profiles/diag_phases.py"""
+MZS_LIB=$PWD/muzero_amd/libmzsearch_diag.so python profiles/diag_phases.py [weights tag]"""
 import ctypes as C
 import os
 import sys
@@ -12,10 +12,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from muzero_amd import _lib, rng  # noqa: E402
 from muzero_amd.engine import SearchEngine  # noqa: E402
 
-w = np.load("tests/golden/weights_tag123.npz")
-dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L"))
+tag = sys.argv[1] if len(sys.argv) > 1 else "tag123"
+w = np.load(f"tests/golden/weights_{tag}.npz")
+dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (int(w["kind"]) if "kind" in w.files else 0,)
 G, S = 4096, 50
-obs = np.random.RandomState(1000).uniform(-0.05, 0.05, size=(G, 4)).astype(np.float32)
+obs = np.random.RandomState(1000).uniform(-0.05, 0.05, size=(G, dims[0])).astype(np.float32)
 dirichlet, noise = rng.noise_streams(np.arange(G), 2, S, 0.25, True)
 eng = SearchEngine(dims, G, S, discount=0.997)
 eng.set_weights(w["blob"])
@@ -26,10 +27,11 @@ for it in range(3):
     eng.results_host()
     lib.mzs_debug_counters(out)
 v = np.array(list(out), dtype=np.float64)
-# k_search_quad: one wave = 4 games; counters are summed over waves (lane 0 of each)
-v[3] -= v[2]
+# one wave = 4 games; counters are summed over waves (lane 0 of each)
+if tag == "tag123":
+    v[3] -= v[2]   # k_search_quad stamps dynamics + prediction together in slot 3
 names = ["-", "select", "dynamics", "prediction", "expand+backup", "-", "-", "-"]
-tot = v.sum()
+tot = v[1:5].sum()
 W = G / 4
 for n, x in zip(names, v):
     if x:

@@ -253,7 +253,7 @@ def test_full_size_4096_games_vs_oracle(tag):
     """BASELINE config C2: 4096 games x 50 simulations against the oracle on all games (bit-exact),
     plus size-independent invariants — tag-123 weights (the benchmark: k_search_quad), and the same
     size on the tied-mid-layer variant (tag 133), the wide kernel (tag 127: k_search_quadw) and the
-    LSTM model (generic kernel)."""
+    LSTM model (k_search_quadl)."""
     from muzero_amd import rng
     from oracle import mz_oracle as mzo
     d, blob = fixture_weights(tag)
@@ -286,4 +286,30 @@ def test_full_size_4096_games_vs_oracle(tag):
     assert np.array_equal(out["consumed"], ref["consumed"])
     assert np.array_equal(tree["sim_leaf"], ref["sim_leaf"])
     assert same_bits(tree["value_sum"], ref["node_vsum"])
+    eng.close()
+
+
+@pytest.mark.parametrize("tag", ["tag123", "tag133", "tag127", "lstmA"])
+def test_repeated_launches_agree_with_generic_kernel(tag):
+    """Race screen (tools/cmp_engines.py): three launches of the shape's fast kernel in a row, each
+    compared with the generic one-game-per-wave kernel on all 4096 games — a data race between
+    waves or against an asynchronous copy shows as mismatches that move from launch to launch."""
+    from muzero_amd import rng
+    d, blob = fixture_weights(tag)
+    G, S, A = 4096, 50, 2
+    obs = np.random.RandomState(5).uniform(-0.05, 0.05, size=(G, 4)).astype(np.float32)
+    dirichlet, noise = rng.noise_streams(np.arange(G), A, S, 0.25, True)
+    gen = make_engine(d, G, S, 0.997, engine="generic")
+    gen.set_weights(blob)
+    gen.search(obs, dirichlet, noise, S, True)
+    ref, ref_tree = gen.results_host(), gen.tree_host()
+    gen.close()
+    eng = make_engine(d, G, S, 0.997)
+    eng.set_weights(blob)
+    for _ in range(3):
+        eng.search(obs, dirichlet, noise, S, True)
+        out, tree = eng.results_host(), eng.tree_host()
+        assert np.array_equal(out["visits"], ref["visits"])
+        assert same_bits(out["root_value"], ref["root_value"])
+        assert same_bits(tree["value_sum"], ref_tree["value_sum"])
     eng.close()
