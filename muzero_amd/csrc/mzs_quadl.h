@@ -8,9 +8,7 @@
  * projections are three 64-neuron output groups of one fused layer (columns 0, 64, 128 of
  * LstmHead::gate[0]); a lane holds the same four units of each gate, so the cell step
  * h = sigmoid(o) * tanh(sigmoid(i) * tanh(g)) is lane-local.  Every unit of the weight stream is a
- * single chunk (fan-in <= 64): it consumes one buffer and requests the next unit's rows into the
- * other, so the buffers swap roles from unit to unit (four units per head: the roles are back
- * where they started after each head).
+ * single chunk (fan-in <= 64); four units per head, so every head starts in stream phase 0.
  * Compile-time S_dim (<= 32... 64), H (<= 64) and A; one LSTM layer (number_of_hidden_layer = 1).
  *
  * Reference code restated (file:line in /root/reference): neural_network_lstm_model.py:10-80,
@@ -23,7 +21,7 @@
 
 namespace mzs {
 
-/* the small vectors of one head in the simulation loop (store or the block's LDS copy: WideTabs) */
+/* the small vectors of one head in the simulation loop (the block's LDS copy: WideTabs) */
 struct LstmHeadTabs {
     const float *lin_b, *gate_b, *bhh; /* Linear bias [64], bias_ih [192], bias_hh [192] */
     const float* extra;                /* [A][64]: the action rows of the Linear (dynamics heads), else null */
@@ -34,33 +32,30 @@ struct LstmTabs {
 constexpr int kLstmHeadTabFloats = 64 + 192 + 192; /* + A * 64 for the two dynamics heads */
 
 /* one head on the input row xrow (LDS, KIN values): h of the LSTM layer, units n0..n0+3 of this
- * lane's game.  Weight stream: X = the head's Linear chunk on entry, the first chunk of `next` (a
- * Linear with fan-in KN, row stride 64) on exit; Y is scratch.  trow: the game's 64-float row for
- * the Linear's output (the B operand of the gates). */
-template <int KIN, int H, int KN, class St>
-__device__ __forceinline__ f32x4 lstm_head_quad(St& st, const Model& m, const LstmHead& hd, const LstmHeadTabs& ht,
-                                                const float* xrow, int action, float* trow, const QuadLane& q,
-                                                float (&X)[64], float (&Y)[64], WideGlobalPtr next) {
+ * lane's game.  Four single-chunk units of the weight stream (Linear, then the i, g, o gate
+ * projections): phases 0..3, so every head starts in phase 0; the o unit's request is the next
+ * head's Linear (KN rows).  trow: the game's 64-float row for the Linear's output (the B operand
+ * of the gates). */
+template <int KIN, int H, int KN>
+__device__ __forceinline__ f32x4 lstm_head_quad(WideStream& st, const LstmHeadTabs& ht, const float* xrow, int action,
+                                                float* trow, const QuadLane& q) {
     static_assert(H <= 64 && KIN <= 64, "single-chunk units");
-    const float* __restrict__ w = m.w;
-    WideGlobalPtr gates = wide_base(w + hd.gate[0].w_off);
     const auto ld4 = [&](const float* p) {
         const float4 v = *reinterpret_cast<const float4*>(p + q.n0);
-        f32x4 r = f32x4{v.x, v.y, v.z, v.w};
-        return r;
+        return f32x4{v.x, v.y, v.z, v.w};
     };
     const f32x4 bi = ld4(ht.bhh), bg = ld4(ht.bhh + 64), bo = ld4(ht.bhh + 128);
     f32x4 c = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     if (action >= 0) c = ld4(ht.extra + action * 64); /* one-hot action column of the dynamics heads */
-    f32x4 lin = wide_unit<KIN, 64, H, 192>(st, wide_base(w + hd.lin.w_off), ht.lin_b + q.n0, xrow, q, X, Y, gates);
+    f32x4 lin = wide_unit<KIN, 0>(st, ht.lin_b + q.n0, xrow, q);
     if (action >= 0) lin = lin + c;
     wave_sync();
     store4(trow + q.n0, lin);
     wave_sync();
     const float* gb = ht.gate_b + q.n0; /* bias_ih; bias_hh after the chain */
-    const f32x4 gi = wide_unit<H, 192, H, 192>(st, gates, gb, trow, q, Y, X, gates + 64);
-    const f32x4 gg = wide_unit<H, 192, H, 192>(st, gates + 64, gb + 64, trow, q, X, Y, gates + 128);
-    const f32x4 go = wide_unit<H, 192, KN, 64>(st, gates + 128, gb + 128, trow, q, Y, X, next);
+    const f32x4 gi = wide_unit<H, 1>(st, gb, trow, q);
+    const f32x4 gg = wide_unit<H, 2>(st, gb + 64, trow, q);
+    const f32x4 go = wide_unit<H, 3, KN>(st, gb + 128, trow, q);
     return f32x4{mzs_lstm_cell0(gi[0] + bi[0], gg[0] + bg[0], go[0] + bo[0]),
                  mzs_lstm_cell0(gi[1] + bi[1], gg[1] + bg[1], go[1] + bo[1]),
                  mzs_lstm_cell0(gi[2] + bi[2], gg[2] + bg[2], go[2] + bo[2]),
@@ -94,18 +89,16 @@ __device__ __forceinline__ void lstm_representation_quad(const Model& m, const W
 }
 
 /* Dynamics_function: reward head then next-state head (its raw LSTM output is the new hidden
- * state, lstm:49-51).  Stream: X = reward Linear chunk on entry, policy Linear chunk on exit. */
-template <int SD, int H, class St>
-__device__ __forceinline__ float lstm_dynamics_quad(St& st, const Model& m, const LstmTabs& T, const WideBufs& Bf, const QuadLane& q, int action,
-                                                    float* hdst, int hid_stride, float (&X)[64], float (&Y)[64]) {
+ * state, lstm:49-51) */
+template <int SD, int H>
+__device__ __forceinline__ float lstm_dynamics_quad(WideStream& st, const LstmTabs& T, const WideBufs& Bf,
+                                                    const QuadLane& q, int action, float* hdst, int hid_stride) {
     float* xrow = Bf.xin + q.c * kWideX;
     float* trow = Bf.trunk + q.c * kWideTrunk;
     const WideValid vd = wide_valid(q, SD);
-    const f32x4 hr = lstm_head_quad<SD, H, SD>(st, m, m.l_rew, T.rew, xrow, action, trow, q, X, Y,
-                                               wide_base(m.w + m.l_st.lin.w_off));
+    const f32x4 hr = lstm_head_quad<SD, H, SD>(st, T.rew, xrow, action, trow, q);
     const float reward = wide_support_mean(wide_softmax(hr, vd), vd, q, SD);
-    f32x4 hs = lstm_head_quad<SD, H, SD>(st, m, m.l_st, T.st, xrow, action, trow, q, X, Y,
-                                         wide_base(m.w + m.l_pol.lin.w_off));
+    f32x4 hs = lstm_head_quad<SD, H, SD>(st, T.st, xrow, action, trow, q);
 #pragma unroll
     for (int r = 0; r < 4; ++r) hs[r] = vd.v[r] ? hs[r] : 0.0f;
     wave_sync();
@@ -115,26 +108,17 @@ __device__ __forceinline__ float lstm_dynamics_quad(St& st, const Model& m, cons
     return reward;
 }
 
-/* Prediction_function: policy head, value head.  Stream: X = policy Linear chunk on entry, reward
- * Linear chunk (the next simulation's first unit) on exit. */
-template <int SD, int H, class St>
-__device__ __forceinline__ float lstm_prediction_quad(St& st, const Model& m, const LstmTabs& T, const WideBufs& Bf, const QuadLane& q,
-                                                      int n_actions, f32x4* prior, float (&X)[64], float (&Y)[64]) {
+/* Prediction_function: policy head, value head */
+template <int SD, int H>
+__device__ __forceinline__ float lstm_prediction_quad(WideStream& st, const LstmTabs& T, const WideBufs& Bf,
+                                                      const QuadLane& q, int n_actions, f32x4* prior) {
     float* xrow = Bf.xin + q.c * kWideX;
     float* trow = Bf.trunk + q.c * kWideTrunk;
-    const f32x4 hp = lstm_head_quad<SD, H, SD>(st, m, m.l_pol, T.pol, xrow, -1, trow, q, X, Y, wide_base(m.w + m.l_val.lin.w_off));
+    const f32x4 hp = lstm_head_quad<SD, H, SD>(st, T.pol, xrow, -1, trow, q);
     *prior = wide_softmax(hp, wide_valid(q, n_actions));
-    const f32x4 hv = lstm_head_quad<SD, H, SD>(st, m, m.l_val, T.val, xrow, -1, trow, q, X, Y, wide_base(m.w + m.l_rew.lin.w_off));
+    const f32x4 hv = lstm_head_quad<SD, H, SD>(st, T.val, xrow, -1, trow, q);
     const WideValid vd = wide_valid(q, SD);
     return wide_support_mean(wide_softmax(hv, vd), vd, q, SD);
-}
-
-template <int SD, class St>
-__device__ __forceinline__ void lstm_stream_start(St& st, const Model& m, const QuadLane& q, int first_img, float (&X)[64]) {
-    if constexpr (std::is_same<St, ImageStream>::value)
-        st.template start<SD>(first_img, X);
-    else
-        wide_load_chunk<SD, 64, 0>(wide_base(m.w + m.l_pol.lin.w_off), (unsigned)quad_neuron_of_lane(q.lane), X);
 }
 
 }  // namespace mzs

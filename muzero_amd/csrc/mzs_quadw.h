@@ -71,48 +71,41 @@ __device__ __forceinline__ void wide_load_chunk(WideGlobalPtr row0, unsigned n, 
     }
 }
 
-/* ---- where a chunk of weight rows comes from ----------------------------------------------
- * DirectStream: from the device weight store (W^T [k][n_pad]), one 256-byte row per
- * global_load_dword: 64 vector-memory instructions per chunk.  Their issue, not the cache
- * bandwidth, is what such a kernel waits for (measured: ~1100 stall cycles per chunk next to 560
- * cycles of matrix work; TCP traffic at half the L1's rate).
- * ImageStream: from the chunk images of k_build_stream — the weights of one simulation in
- * consumption order, 16 KB per chunk in the layout [k / 4][neuron][4]: a lane fetches four
- * consecutive k of its neuron with one global_load_dwordx4 and the wave's 64 lanes cover one
- * contiguous KiB: 16 instructions per chunk.  (Tried and dropped: one copy per block in an LDS ring
- * filled by LDS-DMA — bit-exact with compiler-visible reads, but four global_load_lds per wave
- * and step plus the barrier cost what the shared copy saves: DESIGN.md 4.) */
+/* ---- the weight stream of the simulation loop --------------------------------------------
+ * The weights one simulation consumes are laid out in consumption order as 16 KB chunk images
+ * (k_build_stream, before every search): 64 rows of one 64-neuron output group in the layout
+ * [k / 4][neuron][4], so a lane fetches four consecutive k of its neuron with one
+ * global_load_dwordx4 and the wave's 64 lanes cover one contiguous KiB — 16 vector-memory
+ * instructions per chunk.  (From the store's W^T rows it takes 64 global_load_dword per chunk, and
+ * their issue — not cache bandwidth — is then what the wave waits for: ~1100 stall cycles per
+ * chunk next to 560 cycles of matrix work.  Tried and dropped as well: one copy per block in an
+ * LDS ring filled by LDS-DMA)
+ * Chunk c lives in register buffer c % kBufs; the step that multiplies chunk c first requests
+ * chunk c + kAhead into the buffer chunk c - 1 has left — across groups, layers, nets and
+ * simulations.  The chunks per net are 2 mod 4 (MLP) or 0 mod 4 (LSTM heads), so the buffer a unit
+ * reads is a compile-time constant (its phase I).  kAhead = 3 (four buffers) measured 1 % faster
+ * than 1: with 16 requests per chunk the wave no longer waits for latency but for the L1's
+ * 64 B/clk — four waves x 16 KB per step = 1024 cycles next to 560 of matrix work. */
 constexpr int kImageFloats = 64 * 64;
-constexpr int kMaxImages = 48;
+constexpr int kMaxImages = 128;
+constexpr int kAhead = 1; /* chunks requested ahead of the one being multiplied (1 or 3) */
+constexpr int kBufs = kAhead + 1;
 
-/* where the small per-unit vectors of the simulation loop live: the store, or the block's LDS
- * copy made at kernel start (image kernels) */
-struct WideTabs {
-    const float *d_in_b, *d_mid_b, *d_heads_b, *p_in_b, *p_mid_b, *p_heads_b; /* biases [128] */
-    const float* d_onehot;                                                    /* [A][128]: the action rows of d_in */
-};
-constexpr int kWideTabFloats = 6 * 128; /* + A * 128 */
-
-struct DirectStream {
-    /* request the chunk that follows the one about to be multiplied */
-    template <int K, int NPAD, int k0>
-    __device__ __forceinline__ void begin(WideGlobalPtr row0, unsigned n, float (&wk)[64]) {
-        wide_load_chunk<K, NPAD, k0>(row0, n, wk);
-    }
-};
-
-struct ImageStream {
+struct WideStream {
     WideGlobalPtr img; /* image 0 + this lane's neuron */
     int n_img, next_img;
+    float w[kBufs][64];
     __device__ __forceinline__ void init(const float* images, int n_images, int lane) {
         img = (WideGlobalPtr)images + 4 * quad_neuron_of_lane(lane);
         n_img = n_images;
         next_img = 0;
     }
-    template <int KV>
-    __device__ __forceinline__ void load(float (&wk)[64]) {
+    /* request the next image's first KV rows into buffer I % kBufs */
+    template <int I, int KV = 64>
+    __device__ __forceinline__ void load() {
         typedef const __attribute__((address_space(1))) f32x4* P4;
         P4 b = (P4)(img + (size_t)next_img * kImageFloats);
+        float(&wk)[64] = w[I % kBufs];
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
             if (4 * j < KV) {
@@ -122,18 +115,23 @@ struct ImageStream {
         }
         next_img = next_img + 1 == n_img ? 0 : next_img + 1;
     }
-    /* the first chunk (image `first`, KV rows used) */
-    template <int KV>
-    __device__ __forceinline__ void start(int first, float (&wk)[64]) {
+    /* the stream starts at image `first` (KV0 rows used) in phase I */
+    template <int I, int KV0>
+    __device__ __forceinline__ void start(int first) {
         next_img = first;
-        load<KV>(wk);
-    }
-    template <int K, int NPAD, int k0>
-    __device__ __forceinline__ void begin(WideGlobalPtr, unsigned, float (&wk)[64]) {
-        load<(K - k0 < 64 ? K - k0 : 64)>(wk);
+        load<I, KV0>();
+        if constexpr (kAhead > 1) load<I + 1>();
+        if constexpr (kAhead > 2) load<I + 2>();
     }
 };
 
+/* where the small per-unit vectors of the simulation loop live: the block's LDS copy made at
+ * kernel start */
+struct WideTabs {
+    const float *d_in_b, *d_mid_b, *d_heads_b, *p_in_b, *p_mid_b, *p_heads_b; /* biases [128] */
+    const float* d_onehot;                                                    /* [A][128]: the action rows of d_in */
+};
+constexpr int kWideTabFloats = 6 * 128; /* + A * 128 */
 
 /* chunk k0 (its weight rows already requested into wk) and the chunks after it: the next chunk's
  * 64 rows are requested before this chunk's MFMAs, so their latency overlaps 512 cycles of matrix
@@ -197,17 +195,6 @@ __device__ __forceinline__ void wide_trunk(const float* __restrict__ w, const La
     wave_sync();
 }
 
-/* ---- the weight stream: every dense unit (one output group of one layer) enters with the
- * first 64 rows of its weights already requested (buffer A) and, before its last chunk's MFMAs,
- * requests the first chunk of the unit that follows it in the simulation — across groups, layers,
- * nets and simulations — so only matrix work and the L2 bandwidth remain, not one L2 latency per
- * unit.  Fan-ins are <= 128 (two chunks). */
-__device__ __forceinline__ WideGlobalPtr wide_base(const float* __restrict__ p) {
-    WideGlobalPtr b = (WideGlobalPtr)p;
-    asm volatile("" : "+s"(b)); /* scalar, opaque: see wide_dense */
-    return b;
-}
-
 /* the matrix work of one chunk: rows k0 .. k0+63 of a layer with fan-in K, in cur */
 template <int K, int k0>
 __device__ __forceinline__ void wide_block(const float (&cur)[64], const float (&x)[16], f32x4& e, f32x4& o) {
@@ -218,54 +205,49 @@ __device__ __forceinline__ void wide_block(const float (&cur)[64], const float (
     __builtin_amdgcn_sched_barrier(0);
 }
 
-/* K > 64: A = this unit's chunk 0 on entry, the next unit's chunk 0 on exit (B is scratch).
- * K <= 64: A = this unit's chunk 0 on entry, B = the next unit's chunk 0 on exit. */
-template <int K, int NPAD, int KN, int NPADN, class St>
-__device__ __forceinline__ f32x4 wide_unit(St& st, WideGlobalPtr base, const float* __restrict__ bias4, const float* xrow,
-                                           const QuadLane& q, float (&A)[64], float (&B)[64], WideGlobalPtr next) {
-    static_assert(K <= 128 && KN <= 128, "two chunks at most");
-    const unsigned n = (unsigned)quad_neuron_of_lane(q.lane);
+/* one dense unit (one 64-neuron output group of a layer with fan-in K <= 128) on the stream: its
+ * first chunk is in buffer I % kBufs; KVL = the rows needed of the chunk its last step requests (the
+ * next unit's first) */
+template <int K, int I, int KVL = 64>
+__device__ __forceinline__ f32x4 wide_unit(WideStream& st, const float* __restrict__ bias4, const float* xrow,
+                                           const QuadLane& q) {
+    static_assert(K <= 128, "two chunks at most");
     const float4 bv = *reinterpret_cast<const float4*>(bias4);
     f32x4 e = f32x4{bv.x, bv.y, bv.z, bv.w}, o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
-    float x[16];
+    float x[16], x2[16];
     quad_load_x(xrow, q.grp, x);
+    if constexpr (K > 64) quad_load_x(xrow + 64, q.grp, x2);
+    /* the requests go out as one burst ahead of the block (scheduling barriers on both sides:
+     * a request issued between two MFMAs holds the matrix pipe for its whole issue time) */
+    __builtin_amdgcn_sched_barrier(0);
+    st.template load<I + kAhead, (K > 64 || kAhead > 1 ? 64 : KVL)>();
+    __builtin_amdgcn_sched_barrier(0);
+    wide_block<K, 0>(st.w[I % kBufs], x, e, o);
     if constexpr (K > 64) {
-        float x2[16];
-        quad_load_x(xrow + 64, q.grp, x2);
-        st.template begin<K, NPAD, 64>(base, n, B);
-        wide_block<K, 0>(A, x, e, o);
-        st.template begin<KN, NPADN, 0>(next, n, A);
-        wide_block<K, 64>(B, x2, e, o);
-    } else {
-        st.template begin<KN, NPADN, 0>(next, n, B);
-        wide_block<K, 0>(A, x, e, o);
+        st.template load<I + 1 + kAhead, (kAhead > 1 ? 64 : KVL)>();
+        __builtin_amdgcn_sched_barrier(0);
+        wide_block<K, 64>(st.w[(I + 1) % kBufs], x2, e, o);
     }
     __builtin_amdgcn_sched_barrier(0);
     return e + o;
 }
 
-/* wide_trunk on the weight stream, two output groups (NPAD = 128): A holds group 0's first chunk on
- * entry and the first chunk of `next` (a unit with fan-in KN, row stride NPADN) on exit */
-template <int K, int KN, int NPADN, class St>
-__device__ __forceinline__ void wide_trunk_pf(St& st, const float* __restrict__ wl, const float* bias_row,
-                                              const float* extra, const float* xrow, float* trunk_row,
-                                              const QuadLane& q, float (&A)[64], float (&B)[64], WideGlobalPtr next) {
-    constexpr int NPAD = 128;
-    WideGlobalPtr b0 = wide_base(wl), b1 = b0 + 64;
+/* trunk layer with two output groups (H <= 128) + ELU -> the game's trunk row; extra: the one-hot
+ * action row of this lane's game (added after the chains) or null.  The accumulators of both
+ * groups are complete before the row is overwritten (the mid layer reads and writes it). */
+template <int K, int I>
+__device__ __forceinline__ void wide_trunk_pf(WideStream& st, const float* bias_row, const float* extra,
+                                              const float* xrow, float* trunk_row, const QuadLane& q) {
+    constexpr int I1 = K > 64 ? I + 2 : I + 1;
     const float* bias = bias_row + q.n0;
     f32x4 acc[2];
     float4 c[2];
-    if (extra) { /* the one-hot action row (wave-uniform presence, per-game row): read before the units */
+    if (extra) {
         c[0] = *reinterpret_cast<const float4*>(extra + q.n0);
         c[1] = *reinterpret_cast<const float4*>(extra + 64 + q.n0);
     }
-    if constexpr (K > 64) {
-        acc[0] = wide_unit<K, NPAD, K, NPAD>(st, b0, bias, xrow, q, A, B, b1);
-        acc[1] = wide_unit<K, NPAD, KN, NPADN>(st, b1, bias + 64, xrow, q, A, B, next);
-    } else {
-        acc[0] = wide_unit<K, NPAD, K, NPAD>(st, b0, bias, xrow, q, A, B, b1);
-        acc[1] = wide_unit<K, NPAD, KN, NPADN>(st, b1, bias + 64, xrow, q, B, A, next);
-    }
+    acc[0] = wide_unit<K, I>(st, bias, xrow, q);
+    acc[1] = wide_unit<K, I1>(st, bias + 64, xrow, q);
     if (extra) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
@@ -375,25 +357,20 @@ __device__ __forceinline__ void wide_representation(const Model& m, const WideBu
 
 /* Dynamics_function on the hidden state in the game's xin row + action: the new hidden state
  * replaces it (and goes to the global row hdst); returns the reward's support expectation.
- * Weight stream: A = d_in group 0 chunk 0 on entry, p_in group 0 chunk 0 on exit. */
-template <int SD, int H, class St>
-__device__ __forceinline__ float wide_dynamics(St& st, const Model& m, const WideTabs& T, const WideBufs& Bf,
-                                               const QuadLane& q, int action, float* hdst, float (&A)[64],
-                                               float (&B)[64]) {
+ * Stream phase I (an even number of chunks: 2 + 4 L + 4). */
+template <int SD, int H, int I>
+__device__ __forceinline__ float wide_dynamics(WideStream& st, const Model& m, const WideTabs& T, const WideBufs& Bf,
+                                               const QuadLane& q, int action, float* hdst) {
     static_assert(H > 64 && H <= 128 && SD <= 64, "two trunk groups, one chunk of state inputs");
     float* xrow = Bf.xin + q.c * kWideX;
     float* trow = Bf.trunk + q.c * kWideTrunk;
-    WideGlobalPtr heads = wide_base(m.w + m.d_heads.w_off), mid = wide_base(m.w + m.d_mid.w_off);
-    wide_trunk_pf<SD, H, 128>(st, m.w + m.d_in.w_off, T.d_in_b, T.d_onehot + action * 128, xrow, trow, q, A, B,
-                              m.L > 0 ? mid : heads);
-    for (int l = 0; l < m.L; ++l)
-        wide_trunk_pf<H, H, 128>(st, m.w + m.d_mid.w_off, T.d_mid_b, nullptr, trow, trow, q, A, B,
-                                 l + 1 < m.L ? mid : heads);
+    wide_trunk_pf<SD, I>(st, T.d_in_b, T.d_onehot + action * 128, xrow, trow, q);
+    for (int l = 0; l < m.L; ++l) wide_trunk_pf<H, I + 2>(st, T.d_mid_b, nullptr, trow, trow, q);
     const WideValid vd = wide_valid(q, SD);
     const float* hb = T.d_heads_b + q.n0;
-    const f32x4 ar = wide_unit<H, 128, H, 128>(st, heads, hb, trow, q, A, B, heads + 64);
+    const f32x4 ar = wide_unit<H, I + 2>(st, hb, trow, q);
     const float reward = wide_support_mean(wide_softmax(ar, vd), vd, q, SD);
-    const f32x4 as = wide_unit<H, 128, SD, 128>(st, heads + 64, hb + 64, trow, q, A, B, wide_base(m.w + m.p_in.w_off));
+    const f32x4 as = wide_unit<H, I + 4>(st, hb + 64, trow, q);
     const f32x4 y = wide_scale_to_bound(as, vd);
     wave_sync();
     store4(xrow + q.n0, y);
@@ -403,35 +380,20 @@ __device__ __forceinline__ float wide_dynamics(St& st, const Model& m, const Wid
 }
 
 /* Prediction_function on the hidden state in the game's xin row: priors of actions 0..3 in the
- * lanes with n0 == 0; returns the value's support expectation.  Weight stream: A = p_in group 0
- * chunk 0 on entry, d_in group 0 chunk 0 (the next simulation's first unit) on exit. */
-template <int SD, int H, class St>
-__device__ __forceinline__ float wide_prediction(St& st, const Model& m, const WideTabs& T, const WideBufs& Bf,
-                                                 const QuadLane& q, int n_actions, f32x4* prior, float (&A)[64],
-                                                 float (&B)[64]) {
+ * lanes with n0 == 0; returns the value's support expectation. */
+template <int SD, int H, int I>
+__device__ __forceinline__ float wide_prediction(WideStream& st, const Model& m, const WideTabs& T, const WideBufs& Bf,
+                                                 const QuadLane& q, int n_actions, f32x4* prior) {
     float* xrow = Bf.xin + q.c * kWideX;
     float* trow = Bf.trunk + q.c * kWideTrunk;
-    WideGlobalPtr heads = wide_base(m.w + m.p_heads.w_off), mid = wide_base(m.w + m.p_mid.w_off);
-    wide_trunk_pf<SD, H, 128>(st, m.w + m.p_in.w_off, T.p_in_b, nullptr, xrow, trow, q, A, B, m.L > 0 ? mid : heads);
-    for (int l = 0; l < m.L; ++l)
-        wide_trunk_pf<H, H, 128>(st, m.w + m.p_mid.w_off, T.p_mid_b, nullptr, trow, trow, q, A, B,
-                                 l + 1 < m.L ? mid : heads);
+    wide_trunk_pf<SD, I>(st, T.p_in_b, nullptr, xrow, trow, q);
+    for (int l = 0; l < m.L; ++l) wide_trunk_pf<H, I + 2>(st, T.p_mid_b, nullptr, trow, trow, q);
     const float* hb = T.p_heads_b + q.n0;
-    const f32x4 ap = wide_unit<H, 128, H, 128>(st, heads, hb, trow, q, A, B, heads + 64);
+    const f32x4 ap = wide_unit<H, I + 2>(st, hb, trow, q);
     *prior = wide_softmax(ap, wide_valid(q, n_actions));
     const WideValid vd = wide_valid(q, SD);
-    const f32x4 av = wide_unit<H, 128, SD, 128>(st, heads + 64, hb + 64, trow, q, A, B, wide_base(m.w + m.d_in.w_off));
+    const f32x4 av = wide_unit<H, I + 4>(st, hb + 64, trow, q);
     return wide_support_mean(wide_softmax(av, vd), vd, q, SD);
-}
-
-/* request the first chunk of the prediction net's first unit (before the root's prediction);
- * image stream: image `first_img` (the prediction net's first unit in the stream's order) */
-template <int SD, int H, class St>
-__device__ __forceinline__ void wide_stream_start(St& st, const Model& m, const QuadLane& q, int first_img, float (&A)[64]) {
-    if constexpr (std::is_same<St, ImageStream>::value)
-        st.template start<SD>(first_img, A);
-    else
-        wide_load_chunk<SD, 128, 0>(wide_base(m.w + m.p_in.w_off), (unsigned)quad_neuron_of_lane(q.lane), A);
 }
 
 }  // namespace mzs

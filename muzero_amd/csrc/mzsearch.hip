@@ -504,7 +504,7 @@ __device__ __forceinline__ const float* tab_copy(float*& cursor, const float* sr
  * k_search_quadw: four games per wave for wide MLPs (mzs_quadw.h): weights streamed from the
  * store, hidden states in the global SoA array, trees in LDS.  Same search code as k_search_quad.
  * ---------------------------------------------------------------------------- */
-template <int SD, int NA, int H, bool kImages>
+template <int SD, int NA, int H>
 __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, const QuadLayout ql) {
     extern __shared__ __align__(16) unsigned char smem[];
     const QuadLane q = quad_lane();
@@ -512,24 +512,19 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
     const Model& m = p.m;
     const int S = p.S;
 
+    /* block-shared tables: pb_c / reciprocals, and the small vectors of the simulation loop */
     quad_fill_tables(smem, ql, p);
     WideTabs T;
     {
         const float* w = m.w;
-        if constexpr (kImages) {
-            float* cur = reinterpret_cast<float*>(smem + ql.off_tabs);
-            T.d_in_b = tab_copy(cur, w + m.d_in.b_off, 128);
-            T.d_mid_b = tab_copy(cur, w + m.d_mid.b_off, 128);
-            T.d_heads_b = tab_copy(cur, w + m.d_heads.b_off, 128);
-            T.p_in_b = tab_copy(cur, w + m.p_in.b_off, 128);
-            T.p_mid_b = tab_copy(cur, w + m.p_mid.b_off, 128);
-            T.p_heads_b = tab_copy(cur, w + m.p_heads.b_off, 128);
-            T.d_onehot = tab_copy(cur, w + m.d_in.w_off + SD * 128, NA * 128);
-        } else {
-            T.d_in_b = w + m.d_in.b_off, T.d_mid_b = w + m.d_mid.b_off, T.d_heads_b = w + m.d_heads.b_off;
-            T.p_in_b = w + m.p_in.b_off, T.p_mid_b = w + m.p_mid.b_off, T.p_heads_b = w + m.p_heads.b_off;
-            T.d_onehot = w + m.d_in.w_off + SD * 128;
-        }
+        float* cur = reinterpret_cast<float*>(smem + ql.off_tabs);
+        T.d_in_b = tab_copy(cur, w + m.d_in.b_off, 128);
+        T.d_mid_b = tab_copy(cur, w + m.d_mid.b_off, 128);
+        T.d_heads_b = tab_copy(cur, w + m.d_heads.b_off, 128);
+        T.p_in_b = tab_copy(cur, w + m.p_in.b_off, 128);
+        T.p_mid_b = tab_copy(cur, w + m.p_mid.b_off, 128);
+        T.p_heads_b = tab_copy(cur, w + m.p_heads.b_off, 128);
+        T.d_onehot = tab_copy(cur, w + m.d_in.w_off + SD * 128, NA * 128);
     }
     __syncthreads();
 
@@ -541,8 +536,8 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
     WideBufs B;
     B.trunk = L.trunk;
     B.xin = L.trunk + 4 * kWideTrunk;
-    typename std::conditional<kImages, ImageStream, DirectStream>::type st;
-    if constexpr (kImages) st.init(p.img, p.n_img, q.lane);
+    WideStream st;
+    st.init(p.img, p.n_img, q.lane);
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
     const int noise_cap = p.noise ? (int)p.noise_stride : 0;
@@ -553,14 +548,14 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
     quad_tree_init(L, q, p.n_nodes);
     double nz = S > 0 ? quad_noise_prefetch<NA>(s, q, noise, noise_cap) : 0.0;
 
-    /* root: representation -> prediction -> expand (mcts.py:88-123) */
+    /* root: representation -> prediction -> expand (mcts.py:88-123).  The weight stream starts at
+     * the prediction net (every net has an even number of chunks: phase 0) */
     f32x4 pr;
     for (int k = q.b; k < kWideX; k += 16) xrow[k] = k < m.obs_dim ? p.obs[(size_t)g * m.obs_dim + k] : 0.0f;
     wave_sync();
     wide_representation<SD, H>(m, B, q, hid_g);
-    float wsa[64], wsb[64]; /* the weight stream's two chunk buffers (mzs_quadw.h) */
-    wide_stream_start<SD, H>(st, m, q, p.first_img, wsa);
-    (void)wide_prediction<SD, H>(st, m, T, B, q, NA, &pr, wsa, wsb);
+    st.template start<6 % kBufs, SD>(p.first_img);
+    (void)wide_prediction<SD, H, 6 % kBufs>(st, m, T, B, q, NA, &pr);
     quad_root_expand<NA>(L, s, q, p, g, pr);
 
 #ifdef MZS_DIAG
@@ -578,9 +573,9 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
         *reinterpret_cast<float4*>(xrow + 4 * q.b) = hv;
         wave_sync();
         DIAG_T(t1);
-        const float yr = wide_dynamics<SD, H>(st, m, T, B, q, sel.action, hid_g + (size_t)e_new * p.t.hid_stride, wsa, wsb);
+        const float yr = wide_dynamics<SD, H, 0>(st, m, T, B, q, sel.action, hid_g + (size_t)e_new * p.t.hid_stride);
         DIAG_T(t2);
-        const float yv = wide_prediction<SD, H>(st, m, T, B, q, NA, &pr, wsa, wsb);
+        const float yv = wide_prediction<SD, H, 6 % kBufs>(st, m, T, B, q, NA, &pr);
         DIAG_T(t3);
         float reward, value;
         halves_pair(quad_inverse_value_transform(q.half ? yv : yr), reward, value);
@@ -593,7 +588,6 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
         DIAG_ADD(4, t3, t4);
     }
 #ifdef MZS_DIAG
-
     if (q.lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&g_diag[i], dsum[i]);
 #endif
@@ -604,7 +598,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
  * k_search_quadl: four games per wave for the 'lstm_model' (mzs_quadl.h): the structure of
  * k_search_quadw with the LSTM heads.
  * ---------------------------------------------------------------------------- */
-template <int SD, int NA, int H, bool kImages>
+template <int SD, int NA, int H>
 __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, const QuadLayout ql) {
     extern __shared__ __align__(16) unsigned char smem[];
     const QuadLane q = quad_lane();
@@ -619,15 +613,10 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
         float* cur = reinterpret_cast<float*>(smem + ql.off_tabs);
         const auto head = [&](const LstmHead& hd, bool acts) {
             LstmHeadTabs t;
-            if constexpr (kImages) {
-                t.lin_b = tab_copy(cur, w + hd.lin.b_off, 64);
-                t.gate_b = tab_copy(cur, w + hd.gate[0].b_off, 192);
-                t.bhh = tab_copy(cur, w + hd.bhh_off[0], 192);
-                t.extra = acts ? tab_copy(cur, w + hd.lin.w_off + SD * 64, NA * 64) : nullptr;
-            } else {
-                t.lin_b = w + hd.lin.b_off, t.gate_b = w + hd.gate[0].b_off, t.bhh = w + hd.bhh_off[0];
-                t.extra = acts ? w + hd.lin.w_off + SD * 64 : nullptr;
-            }
+            t.lin_b = tab_copy(cur, w + hd.lin.b_off, 64);
+            t.gate_b = tab_copy(cur, w + hd.gate[0].b_off, 192);
+            t.bhh = tab_copy(cur, w + hd.bhh_off[0], 192);
+            t.extra = acts ? tab_copy(cur, w + hd.lin.w_off + SD * 64, NA * 64) : nullptr;
             return t;
         };
         T.rew = head(m.l_rew, true), T.st = head(m.l_st, true), T.pol = head(m.l_pol, false), T.val = head(m.l_val, false);
@@ -642,8 +631,8 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
     WideBufs B;
     B.trunk = L.trunk;
     B.xin = L.trunk + 4 * kWideTrunk;
-    typename std::conditional<kImages, ImageStream, DirectStream>::type st;
-    if constexpr (kImages) st.init(p.img, p.n_img, q.lane);
+    WideStream st;
+    st.init(p.img, p.n_img, q.lane);
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
     const int noise_cap = p.noise ? (int)p.noise_stride : 0;
@@ -658,9 +647,8 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
     for (int k = q.b; k < kWideX; k += 16) xrow[k] = k < m.obs_dim ? p.obs[(size_t)g * m.obs_dim + k] : 0.0f;
     wave_sync();
     lstm_representation_quad<SD>(m, B, q, hid_g, hs);
-    float wsa[64], wsb[64]; /* the weight stream's two chunk buffers */
-    lstm_stream_start<SD>(st, m, q, p.first_img, wsa);
-    (void)lstm_prediction_quad<SD, H>(st, m, T, B, q, NA, &pr, wsa, wsb);
+    st.template start<0, SD>(p.first_img); /* the policy head's Linear: every head starts in phase 0 */
+    (void)lstm_prediction_quad<SD, H>(st, T, B, q, NA, &pr);
     quad_root_expand<NA>(L, s, q, p, g, pr);
 
     for (int sim = 0; sim < S; ++sim) {
@@ -673,8 +661,8 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
         if (4 * q.b < hs) hv = *reinterpret_cast<const float4*>(hid_g + (size_t)e_parent * hs + 4 * q.b);
         *reinterpret_cast<float4*>(xrow + 4 * q.b) = hv;
         wave_sync();
-        const float yr = lstm_dynamics_quad<SD, H>(st, m, T, B, q, sel.action, hid_g + (size_t)e_new * hs, hs, wsa, wsb);
-        const float yv = lstm_prediction_quad<SD, H>(st, m, T, B, q, NA, &pr, wsa, wsb);
+        const float yr = lstm_dynamics_quad<SD, H>(st, T, B, q, sel.action, hid_g + (size_t)e_new * hs, hs);
+        const float yv = lstm_prediction_quad<SD, H>(st, T, B, q, NA, &pr);
         float reward, value;
         halves_pair(quad_inverse_value_transform(q.half ? yv : yr), reward, value);
         quad_expand<NA>(L, q, sel, sim, pr, reward);
@@ -1104,8 +1092,9 @@ QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model) {
     return l;
 }
 
-/* LDS plan of k_search_quadw: trunk [4][128] and xin [4][64] per wave, trees per game, no hidden
- * states (they live in the global SoA array) */
+/* LDS plan of k_search_quadw / k_search_quadl: block-shared tables (incl. the small vectors of the
+ * simulation loop), trunk [4][128] and xin [4][64] per wave, trees per game, no hidden states (they
+ * live in the global SoA array) */
 QuadLayout make_quadw_layout(int n_nodes, int S, int tab_floats) {
     QuadLayout l;
     l.off_inv64 = round_up((S + 2) * 8, 16);
@@ -1146,20 +1135,19 @@ quad_kernel_t pick_quad_kernel(const mzs_dims& d) {
     return nullptr;
 }
 
-/* wide MLPs (mzs_quadw.h): the shape of experiments 127 / 128.  images: weights from the chunk
- * images (ImageStream), else from the store (DirectStream: models with more than kMaxImages chunks) */
-quad_kernel_t pick_quadw_kernel(const mzs_dims& d, bool images) {
+/* wide MLPs (mzs_quadw.h): the shape of experiments 127 / 128 */
+quad_kernel_t pick_quadw_kernel(const mzs_dims& d) {
     if (d.model_kind != MZS_MODEL_MLP || d.obs_dim > 64) return nullptr;
     if (d.state_dim == 61 && d.hidden_dim == 128 && d.n_actions == 2)
-        return images ? k_search_quadw<61, 2, 128, true> : k_search_quadw<61, 2, 128, false>;
+        return k_search_quadw<61, 2, 128>;
     return nullptr;
 }
 
 /* 'lstm_model' on the weight stream (mzs_quadl.h): one LSTM layer, the shape of the LSTM fixture */
-quad_kernel_t pick_quadl_kernel(const mzs_dims& d, bool images) {
+quad_kernel_t pick_quadl_kernel(const mzs_dims& d) {
     if (d.model_kind != MZS_MODEL_LSTM || d.n_mid_layers != 1 || d.obs_dim > 64) return nullptr;
     if (d.state_dim == 31 && d.hidden_dim == 64 && d.n_actions == 2)
-        return images ? k_search_quadl<31, 2, 64, true> : k_search_quadl<31, 2, 64, false>;
+        return k_search_quadl<31, 2, 64>;
     return nullptr;
 }
 
@@ -1172,7 +1160,7 @@ StreamPlan make_stream_plan(const mzs_dims& d, const Model& m) {
     const auto unit = [&](const Layer& ly, int col, int K) {
         for (int k0 = 0; k0 < K; k0 += 64) v.push_back(StreamUnit{ly.w_off + col, ly.n_pad, K, k0});
     };
-    if (pick_quadw_kernel(d, true)) {
+    if (pick_quadw_kernel(d)) {
         const auto net = [&](const Layer& in, const Layer& mid, const Layer& heads) {
             unit(in, 0, m.Sd), unit(in, 64, m.Sd);
             for (int l = 0; l < m.L; ++l) unit(mid, 0, m.H), unit(mid, 64, m.H);
@@ -1181,7 +1169,7 @@ StreamPlan make_stream_plan(const mzs_dims& d, const Model& m) {
         net(m.d_in, m.d_mid, m.d_heads);
         pl.first = (int)v.size();
         net(m.p_in, m.p_mid, m.p_heads);
-    } else if (pick_quadl_kernel(d, true)) {
+    } else if (pick_quadl_kernel(d)) {
         const auto head = [&](const LstmHead& hd) {
             unit(hd.lin, 0, m.Sd);
             unit(hd.gate[0], 0, m.H), unit(hd.gate[0], 64, m.H), unit(hd.gate[0], 128, m.H);
@@ -1439,26 +1427,22 @@ int mzs_search(mzs_handle* h, int32_t n_games, int32_t S, int32_t train, const f
             const int wpb = quad_waves_per_block(ql);
             if (wpb > 0) return launch_quad(qk, p, ql, wpb, static_cast<hipStream_t>(stream));
         }
-        const bool images = h->stream_plan.n > 0;
-        quad_kernel_t wide = pick_quadw_kernel(h->cfg.dims, images);
-        if (!wide) wide = pick_quadl_kernel(h->cfg.dims, images);
-        if (quad_kernel_t qk = wide) {
+        quad_kernel_t wide = pick_quadw_kernel(h->cfg.dims);
+        if (!wide) wide = pick_quadl_kernel(h->cfg.dims);
+        if (wide && h->stream_plan.n > 0) { /* n == 0: more chunks per simulation than kMaxImages */
             const int A = h->cfg.dims.n_actions;
-            const int tab_floats = !images ? 0
-                                   : h->cfg.dims.model_kind == MZS_MODEL_LSTM ? 4 * kLstmHeadTabFloats + 2 * A * 64
-                                                                              : kWideTabFloats + A * 128;
+            const int tab_floats = h->cfg.dims.model_kind == MZS_MODEL_LSTM ? 4 * kLstmHeadTabFloats + 2 * A * 64
+                                                                            : kWideTabFloats + A * 128;
             const QuadLayout ql = make_quadw_layout(p.n_nodes, S, tab_floats);
             const int wpb = quad_waves_per_block(ql);
             if (wpb > 0) {
-                if (images) {
-                    hipLaunchKernelGGL(k_build_stream, dim3(h->stream_plan.n), dim3(256), 0,
-                                       static_cast<hipStream_t>(stream), h->w_dev, h->stream_plan, h->stream_dev);
-                    HIP_TRY(hipGetLastError());
-                    p.img = h->stream_dev;
-                    p.n_img = h->stream_plan.n;
-                    p.first_img = h->stream_plan.first;
-                }
-                return launch_quad(qk, p, ql, wpb, static_cast<hipStream_t>(stream));
+                hipLaunchKernelGGL(k_build_stream, dim3(h->stream_plan.n), dim3(256), 0,
+                                   static_cast<hipStream_t>(stream), h->w_dev, h->stream_plan, h->stream_dev);
+                HIP_TRY(hipGetLastError());
+                p.img = h->stream_dev;
+                p.n_img = h->stream_plan.n;
+                p.first_img = h->stream_plan.first;
+                return launch_quad(wide, p, ql, wpb, static_cast<hipStream_t>(stream));
             }
         }
     }
