@@ -313,3 +313,32 @@ def test_repeated_launches_agree_with_generic_kernel(tag):
         assert same_bits(out["root_value"], ref["root_value"])
         assert same_bits(tree["value_sum"], ref_tree["value_sum"])
     eng.close()
+
+
+@pytest.mark.parametrize("shape", [(4, 2, 61, 128, 0, 0), (4, 2, 61, 128, 1, 0), (4, 2, 61, 128, 2, 0),
+                                   (17, 2, 61, 128, 1, 0), (4, 2, 61, 128, 15, 0), (4, 2, 31, 64, 1, 1),
+                                   (9, 2, 31, 64, 1, 1)])
+@pytest.mark.parametrize("G,S", [(37, 50), (5, 7), (3, 230)])
+def test_stream_kernel_shapes_vs_oracle(shape, G, S):
+    """The weight-stream kernels (k_search_quadw: S_dim 61 / H 128 with 0, 1, 2 tied mid layers — the
+    chunk count per net decides which register buffer a unit reads; 15 mid layers = more chunks than
+    the image table holds, i.e. the generic kernel; k_search_quadl: the one-layer LSTM), ragged game
+    counts, a deep search (fewer waves per block), seeded random weights: == oracle on every bit."""
+    from muzero_amd import rng
+    from muzero_amd.model import blob_layout
+    from oracle import mz_oracle as mzo
+    d = mzo.dims(*shape)
+    rs = np.random.RandomState(1000 * sum(shape) + 10 * G + S)
+    n_w = sum(int(np.prod(shp)) for _, shp in blob_layout(*shape))
+    blob = (rs.standard_normal(n_w) * (0.1 if shape[4] > 4 else 0.3)).astype(np.float32)
+    obs = rs.uniform(-1, 1, size=(G, shape[0])).astype(np.float32)
+    dirichlet, noise = rng.noise_streams(np.arange(G) + 31, shape[1], S, 0.25, True)
+    eng = make_engine(d, G, S, 0.997)
+    eng.set_weights(blob)
+    eng.search(obs, dirichlet, noise, S, True)
+    out, tree = eng.results_host(), eng.tree_host()
+    ref = mzo.search(d, blob, S, 0.997, 0.25, eng.pbc, obs=obs, dirichlet=dirichlet, noise=noise,
+                     train=True, want=FULL_WANT)
+    assert not tree["status"].any()
+    assert_search_equals_oracle(out, tree, ref)
+    eng.close()
