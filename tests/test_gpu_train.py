@@ -119,3 +119,44 @@ def test_muzero_train_drop_in():
             assert np.all(np.abs(got - L) <= 2e-3 * np.abs(L) + 1e-4)
         assert np.abs(mz.weights_blob() - fx[f"s{s}_blob"]).max() <= (s + 1) * 2e-3 * 0.01 + 1e-6
     assert mz.count == 2
+
+
+def test_training_refreshes_the_weight_stream():
+    """The weight-stream search kernels read chunk images, not the store: a search after a training
+    step must see the new weights (k_build_stream runs before every such search).  Wide shape
+    (S_dim 61 / H 128 / L 1): search, train one step on a synthetic batch, search again — both
+    searches == the oracle's search with the weights read back at that moment, bit for bit."""
+    from muzero_amd import rng
+    from muzero_amd.engine import SearchEngine
+    from muzero_amd.model import blob_layout
+    from muzero_amd.train import Trainer
+    from oracle import mz_oracle as mzo
+    shape, G, S, K, B = (4, 2, 61, 128, 1), 37, 20, 3, 32
+    d = mzo.dims(*shape)
+    rs = np.random.RandomState(4242)
+    n_w = sum(int(np.prod(shp)) for _, shp in blob_layout(*shape))
+    blob0 = (rs.standard_normal(n_w) * 0.2).astype(np.float32)
+    obs = rs.uniform(-1, 1, size=(G, 4)).astype(np.float32)
+    dirichlet, noise = rng.noise_streams(np.arange(G) + 9, 2, S, 0.25, True)
+    eng = SearchEngine(shape, max_games=G, max_simulations=S, discount=0.997)
+    eng.set_weights(blob0)
+    tr = Trainer(eng, K, B, "adam", 0.01, None, 1000)
+
+    def check(blob):
+        eng.search(obs, dirichlet, noise, S, True)
+        out = eng.results_host()
+        ref = mzo.search(d, blob, S, 0.997, 0.25, eng.pbc, obs=obs, dirichlet=dirichlet, noise=noise,
+                         train=True, want=("visits", "root_value"))
+        assert np.array_equal(out["visits"], ref["visits"])
+        assert np.array_equal(np.asarray(out["root_value"]).view(np.uint32), ref["root_value"].view(np.uint32))
+
+    check(blob0)
+    acts = np.zeros((K, B, 2), np.float32)
+    acts[np.arange(K)[:, None], np.arange(B)[None, :], rs.randint(0, 2, size=(K, B))] = 1.0
+    pol = rs.dirichlet([1.0, 1.0], size=(K, B)).astype(np.float32)
+    tr.step(rs.uniform(-1, 1, size=(B, 4)).astype(np.float32), acts,
+            rs.uniform(0, 5, size=(K, B)).astype(np.float32), rs.uniform(0, 1, size=(K, B)).astype(np.float32), pol)
+    blob1 = tr.weights()
+    assert not np.array_equal(blob1, blob0)
+    check(blob1)
+    eng.close()
