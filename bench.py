@@ -2,8 +2,10 @@
 """bench.py — MCTS simulations/sec on the BASELINE.json workload.
 
 One "step" = one batched search: initial inference + S simulations (select,
-recurrent inference, expand, backup) for G games on this rank's GPU, plus the
-result read-back (visit counts / root values to host).  Inputs (observations,
+recurrent inference, expand, backup) for G games on this rank's GPU, with the
+visit counts / root values delivered to pinned host memory (the search kernel
+stores them there itself: mzs_set_result_sink; --copy-back uses a device->host
+copy launch per step instead).  Inputs (observations,
 weights, per-game Dirichlet + tie-break streams) are resident in HBM before the
 timed region.  Games shard over ranks with no collective in the data path.
 
@@ -101,6 +103,7 @@ def main():
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--weights", default="tag123")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--copy-back", action="store_true", help="read results back with a copy launch per step")
     args = ap.parse_args()
 
     import torch
@@ -129,9 +132,11 @@ def main():
     obs_d = torch.as_tensor(obs).to(dev)
     dir_d = torch.as_tensor(dirichlet).to(dev)
     noise_d = torch.as_tensor(noise).to(dev)
-    pack_h = torch.empty(G * (A + 1), dtype=torch.int32).pin_memory()   # visits [G,A] | root values [G]
+    pack_h = torch.zeros(G * (A + 1), dtype=torch.int32).pin_memory()   # visits [G,A] | root values [G]
     visits_h = pack_h[: G * A].view(G, A)
     pack_d = eng.results_packed_view()
+    if not args.copy_back:
+        eng.set_result_sink(visits_h, pack_h[G * A:].view(torch.float32))
 
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
@@ -142,7 +147,8 @@ def main():
         eng.search(obs_d, dir_d, noise_d, S, True)       # the search kernel(s), current stream
         if i is not None:
             ev1[i].record()
-        pack_h.copy_(pack_d, non_blocking=True)           # one 48 KB read-back: visits + root values
+        if args.copy_back:
+            pack_h.copy_(pack_d, non_blocking=True)       # one 48 KB read-back: visits + root values
         return eng.results_view()
 
     def fence():

@@ -68,6 +68,8 @@ struct TreeArrays {
 struct Results {
     int* visits;
     float* root_value;
+    int* visits_sink;       /* mzs_set_result_sink: a second destination (pinned host memory) or null */
+    float* root_value_sink;
     double* root_prior;
     long long* consumed;
     long long* path_len;
@@ -230,11 +232,14 @@ __global__ void __launch_bounds__(256) k_search_fused(const SearchParams p) {
     }
     if (lane < A) {
         p.r.visits[(size_t)g * A + lane] = L.nodes[1 + lane].visit;
+        if (p.r.visits_sink) p.r.visits_sink[(size_t)g * A + lane] = L.nodes[1 + lane].visit;
         p.r.root_prior[(size_t)g * A + lane] = s.root_prior;
     }
     if (lane == 0) {
         const Node r = L.nodes[0];
-        p.r.root_value[g] = r.visit == 0 ? 0.0f : r.vsum / (float)r.visit;
+        const float rv = r.visit == 0 ? 0.0f : r.vsum / (float)r.visit;
+        p.r.root_value[g] = rv;
+        if (p.r.root_value_sink) p.r.root_value_sink[g] = rv;
         p.r.consumed[g] = s.consumed;
         p.r.path_len[g] = s.path_total;
         p.t.minmax[2 * (size_t)g] = s.mn;
@@ -381,11 +386,14 @@ __device__ __forceinline__ void quad_write_out(const SearchParams& p, const Quad
     constexpr int NAL = NA <= 2 ? 2 : 4;
     if (q.b < NAL && q.b < NA) {
         p.r.visits[(size_t)g * NA + q.b] = (int)(L.nodes[1 + q.b].vc >> 16);
+        if (p.r.visits_sink) p.r.visits_sink[(size_t)g * NA + q.b] = (int)(L.nodes[1 + q.b].vc >> 16);
         p.r.root_prior[(size_t)g * NA + q.b] = s.rootp;
     }
     if (q.b == 0) {
         const int rv = (int)(L.nodes[0].vc >> 16);
-        p.r.root_value[g] = rv == 0 ? 0.0f : L.vsum[0] / (float)rv;
+        const float rootv = rv == 0 ? 0.0f : L.vsum[0] / (float)rv;
+        p.r.root_value[g] = rootv;
+        if (p.r.root_value_sink) p.r.root_value_sink[g] = rootv;
         p.r.consumed[g] = s.consumed;
         p.r.path_len[g] = s.path_total;
         p.t.minmax[2 * (size_t)g] = s.mn;
@@ -1474,6 +1482,15 @@ int mzs_search_injected(mzs_handle* h, int32_t n_games, int32_t S, int32_t train
         }
     }
     return launch(k_search_fused<true>, p, n_games, p.lds, static_cast<hipStream_t>(stream));
+}
+
+int mzs_set_result_sink(mzs_handle* h, int32_t* visits, float* root_value) {
+    if (!h) return fail(MZS_E_ARG, "null handle");
+    if ((visits == nullptr) != (root_value == nullptr))
+        return fail(MZS_E_ARG, "pass both sink pointers or neither");
+    h->res.visits_sink = visits;
+    h->res.root_value_sink = root_value;
+    return MZS_OK;
 }
 
 int mzs_results(mzs_handle* h, int32_t n_games, int32_t* visits_dev, float* root_value_dev,

@@ -178,6 +178,23 @@ class SearchEngine:
             self._views = (G, out)
         return self._views[1]
 
+    def set_result_sink(self, visits=None, root_value=None):
+        """mzs_set_result_sink: every later search also stores its visit counts / root values in
+        these pinned host tensors (int32 [max_games, A], float32 [max_games]); they are complete
+        when the search's stream work is (synchronise or wait on an event before reading).
+        None, None switches it off."""
+        if visits is not None:
+            ok = (visits.is_pinned() and root_value.is_pinned() and visits.is_contiguous() and
+                  root_value.is_contiguous() and visits.dtype == torch.int32 and
+                  root_value.dtype == torch.float32 and visits.numel() >= self.max_games * self.A and
+                  root_value.numel() >= self.max_games)
+            if not ok:
+                raise ValueError("result sink: pinned contiguous int32 [max_games, A] and float32 [max_games]")
+        self._sink = (visits, root_value)   # keep the memory alive while the handle points at it
+        _lib.check(self.lib.mzs_set_result_sink(self.h, None if visits is None else visits.data_ptr(),
+                                                None if root_value is None else root_value.data_ptr()),
+                   "mzs_set_result_sink")
+
     def results_packed_view(self):
         """One int32 view [max_games * (A + 1)] over visit counts (max_games x A) followed by the
         root values' bits (max_games): a single device->host copy reads both."""

@@ -342,3 +342,34 @@ def test_stream_kernel_shapes_vs_oracle(shape, G, S):
     assert not tree["status"].any()
     assert_search_equals_oracle(out, tree, ref)
     eng.close()
+
+
+@pytest.mark.parametrize("tag", ["tag123", "tag127"])
+def test_result_sink_matches_device_results(tag):
+    """mzs_set_result_sink: the visit counts and root values the search kernel stores into pinned
+    host memory are the handle's own results, bit for bit (both kernel families), and switching the
+    sink off leaves the host tensors alone."""
+    import torch
+    from muzero_amd import rng
+    d, blob = fixture_weights(tag)
+    G, S, A = 1000, 25, 2
+    obs = np.random.RandomState(3).uniform(-0.05, 0.05, size=(G, 4)).astype(np.float32)
+    dirichlet, noise = rng.noise_streams(np.arange(G), A, S, 0.25, True)
+    eng = make_engine(d, G, S, 0.997)
+    eng.set_weights(blob)
+    vis_h = torch.full((G, A), -1, dtype=torch.int32).pin_memory()
+    val_h = torch.full((G,), -1.0, dtype=torch.float32).pin_memory()
+    eng.set_result_sink(vis_h, val_h)
+    eng.search(obs, dirichlet, noise, S, True)
+    out = eng.results_host()
+    assert np.array_equal(vis_h.numpy(), out["visits"])
+    assert same_bits(val_h.numpy(), out["root_value"])
+    eng.set_result_sink(None, None)
+    vis_h.fill_(-7)
+    eng.search(obs, dirichlet, noise, S, True)
+    out2 = eng.results_host()
+    assert np.array_equal(out2["visits"], out["visits"])
+    assert (vis_h.numpy() == -7).all()
+    with pytest.raises(ValueError):
+        eng.set_result_sink(torch.zeros((G, A), dtype=torch.int32), val_h)   # not pinned
+    eng.close()
