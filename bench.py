@@ -211,8 +211,8 @@ def main():
                            "hbm_equiv": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                          "frac": ach / HBM_PEAK_GBS, "bytes_per_sim": bps},
                            "note": "neither roofline binds at this model size: one wave per SIMD, "
-                                   "instruction issue 61 % / LDS and memory waits 33 % of wave cycles "
-                                   "(profiles/r1e_quad_summary.md, DESIGN.md 4)"}
+                                   "instruction issue 63 % / LDS and memory waits 31 % of wave cycles "
+                                   "(profiles/r1g_quad_summary.md, DESIGN.md 4)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, w["blob"], S, eng.pbc)
         print(json.dumps(out), flush=True)

@@ -106,6 +106,13 @@ int mzs_search_injected(mzs_handle* h, int32_t n_games, int32_t num_simulations,
  *   root_prior_dev [n_games][A] f64  root-child priors after exploration noise
  *   consumed_dev   [n_games] i64     tie-break draws consumed (so the caller can advance its RNG)
  *   path_len_dev   [n_games] i64     total selections made (mean path length = /S) */
+/* Self-test of one assumption of the numeric contract on the device in use: the search kernels
+ * take 1 / visit_count in f64 as hardware estimate + one Newton step, which must equal the
+ * correctly rounded quotient (what NumPy / the oracle compute) for every count a tree can hold.
+ * Evaluates d = 1 .. n_max on the device and counts the mismatches against the host's 1.0 / d.
+ * No counterpart in the reference (pb_c / (n + 1) is Python float division: mcts.py:158). */
+int mzs_selftest_reciprocals(int32_t device, int32_t n_max, int32_t* n_bad);
+
 /* A second destination for the two arrays a caller on the host reads after every search: from
  * now on each search also stores its visit counts ([max_games][A] int32) and root values
  * ([max_games] float) there.  Meant for device-visible host memory (hipHostMalloc / a pinned

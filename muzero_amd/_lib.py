@@ -58,6 +58,7 @@ _SIGNATURES = {
     "mzs_search_injected": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_void_p]),
+    "mzs_selftest_reciprocals": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(C.c_int32)]),
     "mzs_set_result_sink": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "mzs_results": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                               C.c_void_p, C.c_void_p, C.c_void_p]),

@@ -465,6 +465,18 @@ __device__ __forceinline__ void quad_argmax_step(double& bs, int& ba, unsigned& 
     rew = take ? orw : rew;
 }
 
+/* RN(1 / d) in f64 for a visit count d: hardware estimate + one Newton step instead of a second
+ * dependent LDS read per tree level (the table lookup needs the child's record first).  Equal
+ * to the correctly rounded quotient for every 1 <= d <= 65536 — all the counts a tree of at most
+ * 65 535 nodes can hold — which mzs_selftest_reciprocals checks on the device in use
+ * (tests/test_gpu_parity.py). */
+__device__ __forceinline__ double quad_rcp_count(int d) {
+    const double x = (double)d;
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+}
+
 template <int NA>
 struct QuadSelect {
     int leaf, depth, action, pbase;
@@ -473,7 +485,7 @@ struct QuadSelect {
 /* Descent of the four games at once, one tree level per iteration (mcts.py:155-177).
  * Lane (c, a) scores child a of game c's current node; games that reached a leaf idle.
  * Straight-line per level: no data-dependent branches. */
-template <int NA>
+template <int NA, bool kTableRcp = false>
 __device__ __forceinline__ QuadSelect<NA> quad_select(const QuadLds& L, QuadState& s, const QuadLane& q,
                                                       const double* __restrict__ noise, int noise_cap,
                                                       int sim) {
@@ -501,7 +513,9 @@ __device__ __forceinline__ QuadSelect<NA> quad_select(const QuadLds& L, QuadStat
         const QNode ch = L.nodes[child];
         const double tn = L.pbc[pv];
         const int n = (int)(ch.vc >> 16);
-        const double iv = L.inv64[n + 1];
+        /* 1 / (n + 1): computed (no second dependent LDS read per level) unless the kernel has no
+         * registers to spare for it */
+        const double iv = kTableRcp ? L.inv64[n + 1] : quad_rcp_count(n + 1);
         const double u = L.nwin[((t & (kWin - 1)) * NAL + a) * 4 + q.c];
         /* ucb_score (mcts.py:155-163) */
         const double pd = t == 0 ? s.rootp : (double)ch.prior;

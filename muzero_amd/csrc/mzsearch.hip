@@ -273,7 +273,9 @@ __device__ __forceinline__ unsigned long long diag_stamp() {
 /* ---- pieces shared by the four-games-per-wave kernels (k_search_quad, k_search_quadw) ---- */
 
 /* block-shared tables at the start of dynamic LDS: sqrt(n) pb_c(n), 1/n in f64 and f32
- * (correctly rounded reciprocals for div_r*); the caller synchronises the block afterwards */
+ * (correctly rounded reciprocals for div_r*; the selection reads the f64 ones only in the
+ * register-starved kMid kernels, elsewhere it uses quad_rcp_count); the caller synchronises the
+ * block afterwards */
 __device__ __forceinline__ void quad_fill_tables(unsigned char* smem, const QuadLayout& ql, const SearchParams& p) {
     double* pbc_s = reinterpret_cast<double*>(smem);
     double* inv64_s = reinterpret_cast<double*>(smem + ql.off_inv64);
@@ -454,7 +456,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
         DIAG_T(t0);
         L.nwin[q.lane] = nz;
         wave_sync();
-        const QuadSelect<NA> sel = quad_select<NA>(L, s, q, noise, noise_cap, sim);
+        const QuadSelect<NA> sel = quad_select<NA, kMid>(L, s, q, noise, noise_cap, sim);
         nz = quad_noise_prefetch<NA>(s, q, noise, noise_cap);
         DIAG_T(t1);
         const int e_new = sim + 1;
@@ -1267,6 +1269,29 @@ int mzs_debug_counters(unsigned long long* out8) {
     return MZS_OK;
 }
 #endif
+namespace {
+__global__ void k_selftest_reciprocals(int n_max, double* out) {
+    const int d = blockIdx.x * blockDim.x + threadIdx.x + 1;
+    if (d <= n_max) out[d - 1] = quad_rcp_count(d);
+}
+}  // namespace
+
+int mzs_selftest_reciprocals(int32_t device, int32_t n_max, int32_t* n_bad) {
+    if (n_max < 1 || !n_bad) return fail(MZS_E_ARG, "bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    double* dev = nullptr;
+    HIP_TRY(hipMalloc(&dev, (size_t)n_max * sizeof(double)));
+    hipLaunchKernelGGL(k_selftest_reciprocals, dim3((n_max + 255) / 256), dim3(256), 0, nullptr, n_max, dev);
+    std::vector<double> host((size_t)n_max);
+    hipError_t e = hipMemcpy(host.data(), dev, (size_t)n_max * sizeof(double), hipMemcpyDeviceToHost);
+    (void)hipFree(dev);
+    if (e != hipSuccess) return fail(MZS_E_HIP, std::string("selftest copy: ") + hipGetErrorString(e));
+    int bad = 0;
+    for (int d = 1; d <= n_max; ++d) bad += host[(size_t)d - 1] != 1.0 / (double)d;
+    *n_bad = bad;
+    return MZS_OK;
+}
+
 const char* mzs_version(void) { return "mzsearch 0.1 (gfx950)"; }
 
 size_t mzs_weight_count(const mzs_dims* dims) {

@@ -373,3 +373,15 @@ def test_result_sink_matches_device_results(tag):
     with pytest.raises(ValueError):
         eng.set_result_sink(torch.zeros((G, A), dtype=torch.int32), val_h)   # not pinned
     eng.close()
+
+
+def test_device_reciprocals_are_correctly_rounded():
+    """quad_rcp_count (hardware rcp + one Newton step, f64) == 1.0 / d for every visit count a tree
+    can hold (d <= 65536): the one place where the search kernels do not take a quotient from
+    IEEE division or a host-made table."""
+    import ctypes as C
+    from muzero_amd import _lib
+    lib = _lib.load()
+    bad = C.c_int32(-1)
+    _lib.check(lib.mzs_selftest_reciprocals(0, 65536, C.byref(bad)), "mzs_selftest_reciprocals")
+    assert bad.value == 0
