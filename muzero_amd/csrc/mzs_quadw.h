@@ -4,9 +4,11 @@
  *
  * Same lane roles, tree code and arithmetic as mzs_quad.h (bit for bit: include/mzs_numeric.h);
  * what changes is where the operands live:
- *   A operand (weights)  streamed from the device weight store (L2-resident, 324 KB for the shape
- *                        above): one coalesced 256-byte row per MFMA, shared by the four games —
- *                        a quarter of the traffic of the one-game-per-wave generic kernel
+ *   A operand (weights)  streamed from L2: chunk images of the simulation's weights in consumption
+ *                        order (k_build_stream; 320 KB for the shape above), four rows per
+ *                        global_load_dwordx4, each row shared by the four games — a quarter of
+ *                        the traffic of the one-game-per-wave generic kernel (WideStream below);
+ *                        the root's representation net reads the store's W^T rows directly
  *   outputs              H_pad / 64 groups of 64 neurons, one f32x4 accumulator pair each
  *   hidden states        in HBM / L2 (the SoA output array the search fills anyway): 13 KB per
  *                        game would not fit LDS next to the trees of sixteen games
@@ -14,16 +16,14 @@
  *                        column 64 of the fused head layers), reduced over all sixteen lanes of a
  *                        game: half_sum of each half, then the two halves — the contract's
  *                        adjacent-pair tree over a segment padded to 64
- * Compile-time S_dim (32 < S_dim <= 64), H (<= 128) and A, so that every weight row is a
- * constant offset from a wave-uniform base (no per-load address arithmetic) and the fan-in tails
- * generate no guards; obs_dim <= 64 and the number of tied mid layers are runtime values.
+ * Compile-time S_dim (32 < S_dim <= 64), H (<= 128) and A, so that the fan-in tails generate no
+ * guards and every unit knows its register buffer; obs_dim <= 64 and the number of tied mid
+ * layers are runtime values.
  *
  * Reference code restated (file:line in /root/reference): as mzs_device.h.
  */
 #ifndef MZS_QUADW_H
 #define MZS_QUADW_H
-
-#include <utility>
 
 #include "mzs_quad.h"
 
