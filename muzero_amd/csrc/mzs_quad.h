@@ -235,8 +235,79 @@ __device__ __forceinline__ void quad_load_weights(const Model& m, QuadWeights<SD
     }
 }
 
+/* ---- the contract's exp / expm1 / corrected quotient on four values at once: the operation
+ * sequence of mzs_expf / mzs_expm1f_neg / mzs_div_r2 per element (include/mzs_numeric.h), written
+ * on vectors so that the multiplies, adds and fmas pair up into v_pk_{mul,add,fma}_f32 (two IEEE
+ * operations per instruction: same bits, about a third fewer VALU instructions in the layer
+ * epilogues) */
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ f32x4 fma4(const f32x4 a, const f32x4 b, const f32x4 c) {
+    return __builtin_elementwise_fma(a, b, c);
+}
+__device__ __forceinline__ f32x4 splat4(float v) { return f32x4{v, v, v, v}; }
+
+__device__ __forceinline__ f32x4 expm1_poly4(const f32x4 r) {
+    f32x4 p = splat4(1.9875691500e-4f);
+    p = fma4(p, r, splat4(1.3981999507e-3f));
+    p = fma4(p, r, splat4(8.3334519073e-3f));
+    p = fma4(p, r, splat4(4.1665795894e-2f));
+    p = fma4(p, r, splat4(1.6666665459e-1f));
+    p = fma4(p, r, splat4(5.0000001201e-1f));
+    const f32x4 r2 = r * r;
+    return fma4(p, r2, r);
+}
+/* Cody-Waite split of the clamped argument; 2^n of each element in s */
+__device__ __forceinline__ f32x4 exp_reduce4(const f32x4 xc, f32x4* s) {
+    const f32x4 t = xc * splat4(1.44269504088896341f);
+    const f32x4 n = __builtin_elementwise_rint(t);
+    f32x4 r = fma4(n, splat4(-0.693359375f), xc);
+    r = fma4(n, splat4(2.12194440e-4f), r);
+    const i32x4 ni = __builtin_convertvector(n, i32x4);
+    *s = f32x4{mzs_pow2i(ni[0]), mzs_pow2i(ni[1]), mzs_pow2i(ni[2]), mzs_pow2i(ni[3])};
+    return r;
+}
+__device__ __forceinline__ f32x4 clamp4(const f32x4 x, float lo, float hi) {
+    f32x4 y;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) y[i] = __builtin_fmaxf(__builtin_fminf(x[i], hi), lo);
+    return y;
+}
+__device__ __forceinline__ f32x4 expf4(const f32x4 x) {
+    f32x4 s;
+    const f32x4 r = exp_reduce4(clamp4(x, -87.0f, 88.0f), &s);
+    const f32x4 e = expm1_poly4(r) + splat4(1.0f);
+    return e * s;
+}
+__device__ __forceinline__ f32x4 expm1_neg4(const f32x4 x) {
+    f32x4 s;
+    const f32x4 r = exp_reduce4(clamp4(x, -87.0f, 0.0f), &s);
+    return fma4(s, expm1_poly4(r), s - splat4(1.0f));
+}
+/* kPacked = false: the scalar contract functions element by element — for kernels whose register
+ * file is full (the packed forms want aligned register pairs; measured: the kMid kernels and
+ * k_search_quadw lose 2-10 % with them, the others gain 2 %) */
+template <bool kPacked = true>
 __device__ __forceinline__ f32x4 elu4(const f32x4 v) {
-    return f32x4{mzs_elu(v[0]), mzs_elu(v[1]), mzs_elu(v[2]), mzs_elu(v[3])};
+    if constexpr (!kPacked) return f32x4{mzs_elu(v[0]), mzs_elu(v[1]), mzs_elu(v[2]), mzs_elu(v[3])};
+    const f32x4 y = expm1_neg4(v);
+    return f32x4{v[0] > 0.0f ? v[0] : y[0], v[1] > 0.0f ? v[1] : y[1], v[2] > 0.0f ? v[2] : y[2],
+                 v[3] > 0.0f ? v[3] : y[3]};
+}
+template <bool kPacked = true>
+__device__ __forceinline__ f32x4 exp4(const f32x4 x) {
+    if constexpr (!kPacked) return f32x4{mzs_expf(x[0]), mzs_expf(x[1]), mzs_expf(x[2]), mzs_expf(x[3])};
+    return expf4(x);
+}
+/* a[i] / d with r = RN(1 / d) */
+template <bool kPacked = true>
+__device__ __forceinline__ f32x4 div_r2_4(const f32x4 a, float d, float r) {
+    if constexpr (!kPacked)
+        return f32x4{mzs_div_r2(a[0], d, r), mzs_div_r2(a[1], d, r), mzs_div_r2(a[2], d, r), mzs_div_r2(a[3], d, r)};
+    const f32x4 dv = splat4(d), rv = splat4(r);
+    f32x4 q = a * rv;
+    q = fma4(fma4(-q, dv, a), rv, q);
+    return fma4(fma4(-q, dv, a), rv, q);
 }
 
 __device__ __forceinline__ void store4(float* p, const f32x4 v) {
@@ -244,9 +315,10 @@ __device__ __forceinline__ void store4(float* p, const f32x4 v) {
 }
 
 /* ELU(trunk) of the four games -> LDS, back as the B operand of the head layer */
+template <bool kPacked = true>
 __device__ __forceinline__ void quad_trunk_to_x(const QuadLds& L, const QuadLane& q, const f32x4 acc,
                                                 float (&x)[16]) {
-    store4(L.trunk + q.c * 64 + q.n0, elu4(acc));
+    store4(L.trunk + q.c * 64 + q.n0, elu4<kPacked>(acc));
     wave_sync();
     quad_load_x(L.trunk + q.c * 64, q.grp, x);
     wave_sync();
@@ -265,21 +337,16 @@ __device__ __forceinline__ double div_r2(double a, double d, double r) {
 }
 
 /* softmax over the valid logits of this lane's half (contract exp + sum) */
+template <bool kPacked = true>
 __device__ __forceinline__ f32x4 quad_softmax(const f32x4 o, const bool (&valid)[4]) {
     const float ninf = -__builtin_inff();
     const float m = half_max(max4(f32x4{valid[0] ? o[0] : ninf, valid[1] ? o[1] : ninf,
                                         valid[2] ? o[2] : ninf, valid[3] ? o[3] : ninf}));
-    f32x4 e;
+    f32x4 e = exp4<kPacked>(o - splat4(m));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float ex = mzs_expf(o[r] - m);
-        e[r] = valid[r] ? ex : 0.0f;
-    }
+    for (int r = 0; r < 4; ++r) e[r] = valid[r] ? e[r] : 0.0f;
     const float Z = half_sum(sum4(e));
-    const float rz = 1.0f / Z;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) e[r] = div_r2(e[r], Z, rz);
-    return e;
+    return div_r2_4<kPacked>(e, Z, 1.0f / Z);
 }
 
 /* expectation over the support i - SD/2 of probabilities p (muzero_model.py:580-584); the
@@ -314,6 +381,7 @@ __device__ __forceinline__ float quad_inverse_value_transform(float y) {
 }
 
 /* scale_to_bound_action (neural_network_mlp_model.py:135-143) of this lane's half */
+template <bool kPacked = true>
 __device__ __forceinline__ f32x4 quad_scale_to_bound(const f32x4 o, const bool (&valid)[4]) {
     const float ninf = -__builtin_inff();
     const float mx = half_max(max4(f32x4{valid[0] ? o[0] : ninf, valid[1] ? o[1] : ninf,
@@ -321,9 +389,9 @@ __device__ __forceinline__ f32x4 quad_scale_to_bound(const f32x4 o, const bool (
     const float mn = -half_max(max4(f32x4{valid[0] ? -o[0] : ninf, valid[1] ? -o[1] : ninf,
                                           valid[2] ? -o[2] : ninf, valid[3] ? -o[3] : ninf}));
     const float sc = mzs_bound_scale(mn, mx), rs = 1.0f / sc;
-    f32x4 y;
+    f32x4 y = div_r2_4<kPacked>(o - splat4(mn), sc, rs);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) y[r] = valid[r] ? div_r2(o[r] - mn, sc, rs) : 0.0f;
+    for (int r = 0; r < 4; ++r) y[r] = valid[r] ? y[r] : 0.0f;
     return y;
 }
 
@@ -337,17 +405,17 @@ __device__ __forceinline__ float quad_prediction(const QuadWeights<SD, NA, H, kM
     float x[16];
     quad_load_x(h, q.grp & 1, x);
     f32x4 acc = quad_dense<SD>(W.p_in, x, W.b_p_in);
-    quad_trunk_to_x(L, q, acc, x);
+    quad_trunk_to_x<!kMid>(L, q, acc, x);
     if constexpr (kMid) {
         for (int l = 0; l < n_mid; ++l) {
             acc = quad_dense<H>(W.p_mid, x, W.b_p_mid);
-            quad_trunk_to_x(L, q, acc, x);
+            quad_trunk_to_x<!kMid>(L, q, acc, x);
         }
     }
     acc = quad_dense<H>(W.p_h, x, W.b_p_h);
     const int i0 = 4 * q.eb, lim = q.half ? SD : NA;
     const bool valid[4] = {i0 < lim, i0 + 1 < lim, i0 + 2 < lim, i0 + 3 < lim};
-    const f32x4 p = quad_softmax(acc, valid);
+    const f32x4 p = quad_softmax<!kMid>(acc, valid);
     *prior = p;
     const bool vv[4] = {valid[0] && q.half, valid[1] && q.half, valid[2] && q.half, valid[3] && q.half};
     return quad_support_mean<SD>(p, vv, i0);
@@ -366,21 +434,21 @@ __device__ __forceinline__ float quad_dynamics(const QuadWeights<SD, NA, H, kMid
     f32x4 acc = quad_dense<SD>(W.d_in, x, W.b_d_in);
     /* one-hot action column (muzero_model.py:502): fma(1, w, acc) == acc + w */
     acc = f32x4{acc[0] + oh.x, acc[1] + oh.y, acc[2] + oh.z, acc[3] + oh.w};
-    quad_trunk_to_x(L, q, acc, x);
+    quad_trunk_to_x<!kMid>(L, q, acc, x);
     if constexpr (kMid) {
         for (int l = 0; l < n_mid; ++l) {
             acc = quad_dense<H>(W.d_mid, x, W.b_d_mid);
-            quad_trunk_to_x(L, q, acc, x);
+            quad_trunk_to_x<!kMid>(L, q, acc, x);
         }
     }
     acc = quad_dense<H>(W.d_h, x, W.b_d_h);
     const int i0 = 4 * q.eb;
     const bool valid[4] = {i0 < SD, i0 + 1 < SD, i0 + 2 < SD, i0 + 3 < SD};
     /* reward head */
-    const f32x4 p = quad_softmax(acc, valid);
+    const f32x4 p = quad_softmax<!kMid>(acc, valid);
     const float reward = quad_support_mean<SD>(p, valid, i0);
     /* next state */
-    const f32x4 y = quad_scale_to_bound(acc, valid);
+    const f32x4 y = quad_scale_to_bound<!kMid>(acc, valid);
     if (q.half) store4(hn + i0, y);
     wave_sync();
     return reward;

@@ -31,6 +31,21 @@ struct LstmTabs {
 };
 constexpr int kLstmHeadTabFloats = 64 + 192 + 192; /* + A * 64 for the two dynamics heads */
 
+/* mzs_sigmoid / mzs_tanh / mzs_lstm_cell0 (include/mzs_numeric.h) on four values at once: the same
+ * operations per element, on vectors (mzs_quad.h expf4) */
+__device__ __forceinline__ f32x4 sigmoid4(const f32x4 x) { return splat4(1.0f) / (splat4(1.0f) + expf4(-x)); }
+__device__ __forceinline__ f32x4 tanh4(const f32x4 x) {
+    const f32x4 a = __builtin_elementwise_abs(x);
+    const f32x4 t = expm1_neg4(splat4(-2.0f) * a);
+    const f32x4 y = -t / (t + splat4(2.0f));
+    return f32x4{x[0] < 0.0f ? -y[0] : y[0], x[1] < 0.0f ? -y[1] : y[1], x[2] < 0.0f ? -y[2] : y[2],
+                 x[3] < 0.0f ? -y[3] : y[3]};
+}
+__device__ __forceinline__ f32x4 lstm_cell0_4(const f32x4 gi, const f32x4 gg, const f32x4 go) {
+    const f32x4 c = sigmoid4(gi) * tanh4(gg);
+    return sigmoid4(go) * tanh4(c);
+}
+
 /* one head on the input row xrow (LDS, KIN values): h of the LSTM layer, units n0..n0+3 of this
  * lane's game.  Four single-chunk units of the weight stream (Linear, then the i, g, o gate
  * projections): phases 0..3, so every head starts in phase 0; the o unit's request is the next
@@ -56,10 +71,7 @@ __device__ __forceinline__ f32x4 lstm_head_quad(WideStream& st, const LstmHeadTa
     const f32x4 gi = wide_unit<H, 1>(st, gb, trow, q);
     const f32x4 gg = wide_unit<H, 2>(st, gb + 64, trow, q);
     const f32x4 go = wide_unit<H, 3, KN>(st, gb + 128, trow, q);
-    return f32x4{mzs_lstm_cell0(gi[0] + bi[0], gg[0] + bg[0], go[0] + bo[0]),
-                 mzs_lstm_cell0(gi[1] + bi[1], gg[1] + bg[1], go[1] + bo[1]),
-                 mzs_lstm_cell0(gi[2] + bi[2], gg[2] + bg[2], go[2] + bo[2]),
-                 mzs_lstm_cell0(gi[3] + bi[3], gg[3] + bg[3], go[3] + bo[3])};
+    return lstm_cell0_4(gi + bi, gg + bg, go + bo);
 }
 
 /* Representation_function: one Linear, no activation (lstm:19-21); observation in the game's xin
@@ -97,7 +109,7 @@ __device__ __forceinline__ float lstm_dynamics_quad(WideStream& st, const LstmTa
     float* trow = Bf.trunk + q.c * kWideTrunk;
     const WideValid vd = wide_valid(q, SD);
     const f32x4 hr = lstm_head_quad<SD, H, SD>(st, T.rew, xrow, action, trow, q);
-    const float reward = wide_support_mean(wide_softmax(hr, vd), vd, q, SD);
+    const float reward = wide_support_mean(wide_softmax<true>(hr, vd), vd, q, SD);
     f32x4 hs = lstm_head_quad<SD, H, SD>(st, T.st, xrow, action, trow, q);
 #pragma unroll
     for (int r = 0; r < 4; ++r) hs[r] = vd.v[r] ? hs[r] : 0.0f;
@@ -115,10 +127,10 @@ __device__ __forceinline__ float lstm_prediction_quad(WideStream& st, const Lstm
     float* xrow = Bf.xin + q.c * kWideX;
     float* trow = Bf.trunk + q.c * kWideTrunk;
     const f32x4 hp = lstm_head_quad<SD, H, SD>(st, T.pol, xrow, -1, trow, q);
-    *prior = wide_softmax(hp, wide_valid(q, n_actions));
+    *prior = wide_softmax<true>(hp, wide_valid(q, n_actions));
     const f32x4 hv = lstm_head_quad<SD, H, SD>(st, T.val, xrow, -1, trow, q);
     const WideValid vd = wide_valid(q, SD);
-    return wide_support_mean(wide_softmax(hv, vd), vd, q, SD);
+    return wide_support_mean(wide_softmax<true>(hv, vd), vd, q, SD);
 }
 
 }  // namespace mzs

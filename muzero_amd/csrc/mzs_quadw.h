@@ -191,7 +191,7 @@ __device__ __forceinline__ void wide_trunk(const float* __restrict__ w, const La
     }
     wave_sync();
 #pragma unroll
-    for (int g = 0; g < NG; ++g) store4(trunk_row + 64 * g + q.n0, elu4(acc[g]));
+    for (int g = 0; g < NG; ++g) store4(trunk_row + 64 * g + q.n0, elu4<false>(acc[g]));
     wave_sync();
 }
 
@@ -255,7 +255,7 @@ __device__ __forceinline__ void wide_trunk_pf(WideStream& st, const float* bias_
     }
     wave_sync();
 #pragma unroll
-    for (int g = 0; g < 2; ++g) store4(trunk_row + 64 * g + q.n0, elu4(acc[g]));
+    for (int g = 0; g < 2; ++g) store4(trunk_row + 64 * g + q.n0, elu4<false>(acc[g]));
     wave_sync();
 }
 
@@ -270,21 +270,16 @@ __device__ __forceinline__ WideValid wide_valid(const QuadLane& q, int n) {
 }
 
 /* softmax over the n valid logits of a 64-neuron group (contract exp + sum + shared-reciprocal quotient) */
+template <bool kPacked = false>
 __device__ __forceinline__ f32x4 wide_softmax(const f32x4 o, const WideValid& vd) {
     const float ninf = -__builtin_inff();
     const float m = game_max(max4(f32x4{vd.v[0] ? o[0] : ninf, vd.v[1] ? o[1] : ninf, vd.v[2] ? o[2] : ninf,
                                         vd.v[3] ? o[3] : ninf}));
-    f32x4 e;
+    f32x4 e = exp4<kPacked>(o - splat4(m));
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const float ex = mzs_expf(o[r] - m);
-        e[r] = vd.v[r] ? ex : 0.0f;
-    }
+    for (int r = 0; r < 4; ++r) e[r] = vd.v[r] ? e[r] : 0.0f;
     const float Z = game_sum(sum4(e));
-    const float rz = 1.0f / Z;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) e[r] = div_r2(e[r], Z, rz);
-    return e;
+    return div_r2_4<kPacked>(e, Z, 1.0f / Z);
 }
 
 /* expectation over the support i - n/2 (before the inverse value transform) */
@@ -302,9 +297,9 @@ __device__ __forceinline__ f32x4 wide_scale_to_bound(const f32x4 o, const WideVa
     const float mn = -game_max(max4(f32x4{vd.v[0] ? -o[0] : ninf, vd.v[1] ? -o[1] : ninf, vd.v[2] ? -o[2] : ninf,
                                           vd.v[3] ? -o[3] : ninf}));
     const float sc = mzs_bound_scale(mn, mx), rs = 1.0f / sc;
-    f32x4 y;
+    f32x4 y = div_r2_4<false>(o - splat4(mn), sc, rs);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) y[r] = vd.v[r] ? div_r2(o[r] - mn, sc, rs) : 0.0f;
+    for (int r = 0; r < 4; ++r) y[r] = vd.v[r] ? y[r] : 0.0f;
     return y;
 }
 
@@ -343,7 +338,7 @@ __device__ __forceinline__ void wide_representation(const Model& m, const WideBu
         }
         wave_sync();
 #pragma unroll
-        for (int g = 0; g < NG; ++g) store4(trow + 64 * g + q.n0, elu4(acc[g]));
+        for (int g = 0; g < NG; ++g) store4(trow + 64 * g + q.n0, elu4<false>(acc[g]));
         wave_sync();
     }
     wide_mid<H>(m, m.r_mid, trow, q);
