@@ -212,7 +212,7 @@ def main():
                                          "frac": ach / HBM_PEAK_GBS, "bytes_per_sim": bps},
                            "note": "neither roofline binds at this model size: one wave per SIMD, "
                                    "instruction issue 63 % / LDS and memory waits 31 % of wave cycles "
-                                   "(profiles/r1g_quad_summary.md, DESIGN.md 4)"}
+                                   "(profiles/r1h_quad_summary.md, DESIGN.md 4)"}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(dims, w["blob"], S, eng.pbc)
         print(json.dumps(out), flush=True)
