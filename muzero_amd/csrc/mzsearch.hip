@@ -404,7 +404,7 @@ __device__ __forceinline__ void quad_write_out(const SearchParams& p, const Quad
     }
 }
 
-template <int SD, int NA, int H, bool kInjected, bool kMid = false>
+template <int SD, int NA, int H, bool kInjected, bool kMid = false, bool kHidG = false>
 __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, const QuadLayout ql) {
     extern __shared__ __align__(16) unsigned char smem[];
     const QuadLane q = quad_lane();
@@ -427,7 +427,12 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
     if (g0 >= p.n_games) return;
     const bool live = g0 + q.c < p.n_games;          /* dead slots replay the last game, write nothing */
     const int g = live ? g0 + q.c : p.n_games - 1;
-    const QuadLds L = quad_carve(smem, ql, wave, q, true);
+    /* kHidG: the hidden states of the expansions live in the global SoA array (L2) and LDS keeps
+     * one 32-float row per game — for trees whose sixteen games would not fit the CU's LDS next
+     * to 6.5 KB of hidden states each (three or four actions, or more than ~55 simulations) */
+    QuadLds L = quad_carve(smem, ql, wave, q, !kHidG);
+    float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * p.t.hid_stride;
+    if constexpr (kHidG) L.hid = L.trunk + 4 * 64 + q.c * 32;
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
     const int noise_cap = p.noise ? (int)p.noise_stride : 0;
@@ -445,6 +450,9 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
         for (int k = q.b; k < m.obs_dim; k += 16) L.trunk[q.c * 64 + k] = p.obs[(size_t)g * m.obs_dim + k];
         wave_sync();
         quad_representation<SD, NA, H>(m, L, q, L.hid);
+        if constexpr (kHidG) {
+            if (q.b < 8) *reinterpret_cast<float4*>(hid_g + 4 * q.b) = *reinterpret_cast<const float4*>(L.hid + 4 * q.b);
+        }
         (void)quad_prediction<SD, NA, H, kMid>(W, L, q, L.hid, &pr, m.L);   /* the root's value is not used */
     }
     quad_root_expand<NA>(L, s, q, p, g, pr);
@@ -469,8 +477,20 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
         } else {
             /* dynamics on the parent's hidden state, prediction on the new one (mcts.py:180-192) */
             const int e_parent = (sel.pbase - 1) / NA;
-            float* hn = L.hid + e_new * 32;
-            const float yr = quad_dynamics<SD, NA, H, kMid>(W, L, q, L.hid + e_parent * 32, sel.action, hn, m.L);
+            float* hn = kHidG ? L.hid : L.hid + e_new * 32;
+            const float* hp = kHidG ? L.hid : L.hid + e_parent * 32;
+            if constexpr (kHidG) { /* the parent's hidden state: 32 floats per game, four per lane */
+                if (q.b < 8)
+                    *reinterpret_cast<float4*>(L.hid + 4 * q.b) =
+                        *reinterpret_cast<const float4*>(hid_g + (size_t)e_parent * p.t.hid_stride + 4 * q.b);
+                wave_sync();
+            }
+            const float yr = quad_dynamics<SD, NA, H, kMid>(W, L, q, hp, sel.action, hn, m.L);
+            if constexpr (kHidG) {
+                if (q.b < 8)
+                    *reinterpret_cast<float4*>(hid_g + (size_t)e_new * p.t.hid_stride + 4 * q.b) =
+                        *reinterpret_cast<const float4*>(L.hid + 4 * q.b);
+            }
             DIAG_T(t2);
             DIAG_ADD(2, t1, t2);
             const float yv = quad_prediction<SD, NA, H, kMid>(W, L, q, hn, &pr, m.L);
@@ -488,8 +508,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
 
     if (live) {
         quad_write_out<NA>(p, L, s, q, g);
-        if (!kInjected) { /* hidden states of the expansions */
-            float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * p.t.hid_stride;
+        if (!kInjected && !kHidG) { /* hidden states of the expansions */
             for (int i = q.b; i < (S + 1) * 32; i += 16) {
                 const int e = i >> 5, k = i & 31;
                 if (k < SD) hid_g[(size_t)e * p.t.hid_stride + k] = L.hid[i];
@@ -1079,14 +1098,14 @@ int launch(K kernel, const P& params, int units, const LdsLayout& lds, hipStream
 }
 
 /* LDS plan of k_search_quad (mzs_quad.h QuadLayout) */
-QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model) {
+QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model, bool hid_lds = true) {
     QuadLayout l;
     l.off_inv64 = round_up((S + 2) * 8, 16);
     l.off_inv32 = 2 * l.off_inv64;
     l.off_onehot = l.off_inv32 + round_up((S + 2) * 4, 16);
     l.off_tabs = 0;
     l.shared_bytes = l.off_onehot + (with_model ? A * 64 * 4 : 0);
-    l.off_nwin = 4 * 64 * 4;
+    l.off_nwin = 4 * 64 * 4 + (with_model && !hid_lds ? 4 * 32 * 4 : 0); /* + one hidden-state row per game */
     l.off_games = l.off_nwin + 64 * 8;
     int off = n_nodes * (int)sizeof(QNode);
     l.g_vsum = off;
@@ -1094,7 +1113,7 @@ QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model) {
     l.g_path = off;
     off += round_up((S + 2) * 8, 16);
     l.g_hid = off;
-    off += with_model ? (S + 1) * 32 * 4 : 0;
+    off += with_model && hid_lds ? (S + 1) * 32 * 4 : 0;
     l.g_leafs = off;
     off += round_up((S + 1) * 2, 16);
     l.g_bytes = off;
@@ -1129,20 +1148,25 @@ QuadLayout make_quadw_layout(int n_nodes, int S, int tab_floats) {
 
 /* the (S_dim, A, H) shapes the four-games-per-wave kernel is instantiated for */
 typedef void (*quad_kernel_t)(const SearchParams, const QuadLayout);
-quad_kernel_t pick_quad_kernel(const mzs_dims& d) {
+template <bool kHidG>
+quad_kernel_t pick_quad_kernel_t(const mzs_dims& d) {
     if (d.obs_dim > 64 || d.model_kind != MZS_MODEL_MLP) return nullptr;
     const bool mid = d.n_mid_layers != 0; /* tied mid layers (any count): H more register-resident rows per net */
     if (d.state_dim == 31 && d.hidden_dim == 64) {
         switch (d.n_actions) {
-            case 2: return mid ? k_search_quad<31, 2, 64, false, true> : k_search_quad<31, 2, 64, false, false>;
-            case 3: return mid ? k_search_quad<31, 3, 64, false, true> : k_search_quad<31, 3, 64, false, false>;
-            case 4: return mid ? k_search_quad<31, 4, 64, false, true> : k_search_quad<31, 4, 64, false, false>;
+            case 2: return mid ? k_search_quad<31, 2, 64, false, true, kHidG> : k_search_quad<31, 2, 64, false, false, kHidG>;
+            case 3: return mid ? k_search_quad<31, 3, 64, false, true, kHidG> : k_search_quad<31, 3, 64, false, false, kHidG>;
+            case 4: return mid ? k_search_quad<31, 4, 64, false, true, kHidG> : k_search_quad<31, 4, 64, false, false, kHidG>;
             default: return nullptr;
         }
     }
     if (d.state_dim == 11 && d.n_actions == 2 && d.hidden_dim == 16)
-        return mid ? k_search_quad<11, 2, 16, false, true> : k_search_quad<11, 2, 16, false, false>;
+        return mid ? k_search_quad<11, 2, 16, false, true, kHidG> : k_search_quad<11, 2, 16, false, false, kHidG>;
     return nullptr;
+}
+/* hid_global: the variant that keeps the expansions' hidden states in the global SoA array */
+quad_kernel_t pick_quad_kernel(const mzs_dims& d, bool hid_global = false) {
+    return hid_global ? pick_quad_kernel_t<true>(d) : pick_quad_kernel_t<false>(d);
 }
 
 /* wide MLPs (mzs_quadw.h): the shape of experiments 127 / 128 */
@@ -1456,8 +1480,14 @@ int mzs_search(mzs_handle* h, int32_t n_games, int32_t S, int32_t train, const f
     p.obs = obs_dev;
     if (h->cfg.engine == MZS_ENGINE_FUSED && mzs_max_draws(h->cfg.dims.n_actions, S) < (1ll << 31)) {
         if (quad_kernel_t qk = pick_quad_kernel(h->cfg.dims)) {
+            /* sixteen games per CU with their hidden states in LDS if that fits; else the variant
+             * with the hidden states in the global array, if it seats more waves per block */
             const QuadLayout ql = make_quad_layout(p.m.A, p.n_nodes, S, true);
             const int wpb = quad_waves_per_block(ql);
+            const QuadLayout qg = make_quad_layout(p.m.A, p.n_nodes, S, true, false);
+            const int wpg = wpb < 4 ? quad_waves_per_block(qg) : 0;
+            if (wpg > wpb)
+                return launch_quad(pick_quad_kernel(h->cfg.dims, true), p, qg, wpg, static_cast<hipStream_t>(stream));
             if (wpb > 0) return launch_quad(qk, p, ql, wpb, static_cast<hipStream_t>(stream));
         }
         quad_kernel_t wide = pick_quadw_kernel(h->cfg.dims);

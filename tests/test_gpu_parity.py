@@ -195,8 +195,8 @@ def test_quad_shapes_vs_oracle(shape, G, S):
                                      ((4, 2, 31, 64, 0), 400)])
 def test_deep_searches_vs_oracle(shape, S):
     """More simulations than the benchmark's 50: the per-game LDS footprint grows, so the quad kernel
-    runs with fewer waves per block (S = 120: 2, S = 230: 1) and beyond that the engine falls back to
-    the generic kernel (S = 400); every variant == oracle on every output bit."""
+    switches to the variant with the hidden states in the global array (S = 120, 230: still four
+    waves per block; S = 400: fewer); every variant == oracle on every output bit."""
     from muzero_amd import rng
     from muzero_amd.model import blob_layout
     from oracle import mz_oracle as mzo
@@ -289,15 +289,15 @@ def test_full_size_4096_games_vs_oracle(tag):
     eng.close()
 
 
-@pytest.mark.parametrize("tag", ["tag123", "tag133", "tag127", "lstmA"])
+@pytest.mark.parametrize("tag", ["tag123", "tag133", "tag127", "lstmA", "synA4"])
 def test_repeated_launches_agree_with_generic_kernel(tag):
     """Race screen (tools/cmp_engines.py): three launches of the shape's fast kernel in a row, each
     compared with the generic one-game-per-wave kernel on all 4096 games — a data race between
     waves or against an asynchronous copy shows as mismatches that move from launch to launch."""
     from muzero_amd import rng
     d, blob = fixture_weights(tag)
-    G, S, A = 4096, 50, 2
-    obs = np.random.RandomState(5).uniform(-0.05, 0.05, size=(G, 4)).astype(np.float32)
+    G, S, A = 4096, 50, d.n_actions     # synA4: four actions = hidden states in the global array
+    obs = np.random.RandomState(5).uniform(-0.05, 0.05, size=(G, d.obs_dim)).astype(np.float32)
     dirichlet, noise = rng.noise_streams(np.arange(G), A, S, 0.25, True)
     gen = make_engine(d, G, S, 0.997, engine="generic")
     gen.set_weights(blob)
