@@ -42,8 +42,19 @@ def flops_per_sim(A, S_dim, H, L, kind=0):
     return 2 * ((S_dim + A) * H + 2 * H * S_dim + S_dim * H + H * A + H * S_dim) + 2 * H * H * 2 * L
 
 
-def search_kernel_name(obs_dim, A, S_dim, H, L, kind):
+def quad_hidden_in_lds(A, S):
+    """mzsearch.hip make_quad_layout / quad_waves_per_block: do four waves (sixteen games) with their
+    hidden states fit the CU's 160 KB of LDS?  Otherwise mzs_search takes the kHidG variant."""
+    r16 = lambda x: (x + 15) // 16 * 16  # noqa: E731
+    n = 1 + A * (S + 1)
+    shared = 2 * r16((S + 2) * 8) + r16((S + 2) * 4) + A * 64 * 4
+    game = n * 16 + r16(n * 4) + r16((S + 2) * 8) + (S + 1) * 32 * 4 + r16((S + 1) * 2)
+    return shared + 4 * (4 * 64 * 4 + 64 * 8 + 4 * game) <= 160 * 1024
+
+
+def search_kernel_name(obs_dim, A, S_dim, H, L, kind, S=50):
     """The kernel mzs_search dispatches to for these shapes (mzsearch.hip pick_quad_kernel)."""
+    hid = "false" if quad_hidden_in_lds(A, S) else "true"
     shape = (S_dim, A, H)
     quad = kind == 0 and obs_dim <= 64 and shape in ((31, 2, 64), (31, 3, 64), (31, 4, 64), (11, 2, 16))
     mid = "true" if L > 0 else "false"
@@ -51,7 +62,7 @@ def search_kernel_name(obs_dim, A, S_dim, H, L, kind):
         return "k_search_quadw<61,2,128>"
     if kind == 1 and obs_dim <= 64 and (S_dim, A, H, L) == (31, 2, 64, 1):
         return "k_search_quadl<31,2,64>"
-    return f"k_search_quad<{S_dim},{A},{H},false,{mid}>" if quad else "k_search_fused<false>"
+    return f"k_search_quad<{S_dim},{A},{H},false,{mid},{hid}>" if quad else "k_search_fused<false>"
 
 
 def cpu_baseline(dims, blob, S, pbc, seconds_target=12.0):
@@ -120,7 +131,7 @@ def main():
     kind = int(w["kind"]) if "kind" in w.files else 0
     dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (kind,)
     obs_dim, A, S_dim, H, L = dims[:5]
-    kernel_name = search_kernel_name(obs_dim, A, S_dim, H, L, kind)
+    kernel_name = search_kernel_name(obs_dim, A, S_dim, H, L, kind, args.sims)
     model_name = "LSTM" if kind == 1 else "MLP"
     G, S = args.games, args.sims
 
