@@ -9,7 +9,7 @@ copy launch per step instead).  Inputs (observations,
 weights, per-game Dirichlet + tie-break streams) are resident in HBM before the
 timed region.  Games shard over ranks with no collective in the data path.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]      (N > 1: starts the N ranks itself)
   python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
 Rank 0 prints ONE JSON line (see DESIGN.md "Measurement").
@@ -40,29 +40,6 @@ def flops_per_sim(A, S_dim, H, L, kind=0):
             return n_in * H + sum(3 * out * (H if l == 0 else out) for l in range(L))
         return 2 * (2 * head(S_dim + A, S_dim) + head(S_dim, A) + head(S_dim, S_dim))
     return 2 * ((S_dim + A) * H + 2 * H * S_dim + S_dim * H + H * A + H * S_dim) + 2 * H * H * 2 * L
-
-
-def quad_hidden_in_lds(A, S):
-    """mzsearch.hip make_quad_layout / quad_waves_per_block: do four waves (sixteen games) with their
-    hidden states fit the CU's 160 KB of LDS?  Otherwise mzs_search takes the kHidG variant."""
-    r16 = lambda x: (x + 15) // 16 * 16  # noqa: E731
-    n = 1 + A * (S + 1)
-    shared = 2 * r16((S + 2) * 8) + r16((S + 2) * 4) + A * 64 * 4
-    game = n * 16 + r16(n * 4) + r16((S + 2) * 8) + (S + 1) * 32 * 4 + r16((S + 1) * 2)
-    return shared + 4 * (4 * 64 * 4 + 64 * 8 + 4 * game) <= 160 * 1024
-
-
-def search_kernel_name(obs_dim, A, S_dim, H, L, kind, S=50):
-    """The kernel mzs_search dispatches to for these shapes (mzsearch.hip pick_quad_kernel)."""
-    hid = "false" if quad_hidden_in_lds(A, S) else "true"
-    shape = (S_dim, A, H)
-    quad = kind == 0 and obs_dim <= 64 and shape in ((31, 2, 64), (31, 3, 64), (31, 4, 64), (11, 2, 16))
-    mid = "true" if L > 0 else "false"
-    if kind == 0 and obs_dim <= 64 and (S_dim, A, H) == (61, 2, 128):
-        return "k_search_quadw<61,2,128>"
-    if kind == 1 and obs_dim <= 64 and (S_dim, A, H, L) == (31, 2, 64, 1):
-        return "k_search_quadl<31,2,64>"
-    return f"k_search_quad<{S_dim},{A},{H},false,{mid},{hid}>" if quad else "k_search_fused<false>"
 
 
 def cpu_baseline(dims, blob, S, pbc, seconds_target=12.0):
@@ -108,21 +85,33 @@ def cpu_baseline(dims, blob, S, pbc, seconds_target=12.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--games", type=int, default=4096, help="games per GPU")
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--weights", default="tag123")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--copy-back", action="store_true", help="read results back with a copy launch per step")
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
     args = ap.parse_args()
+
+    from muzero_amd import shard
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as the driver calls it: this process becomes the launcher of N
+        # ranks (one per GPU, RCCL).  It has not touched the GPU and never will.
+        sys.exit(shard.launch_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     import torch
     import torch.distributed as dist
-    from muzero_amd import rng, shard
+    from muzero_amd import rng
     from muzero_amd.engine import SearchEngine
 
-    rank, world = shard.init("nccl")          # nccl == RCCL on ROCm; no-op for one rank
+    env_world = shard.rank_world()[1]
+    if env_world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={env_world} ranks")
+    if shard.visible_gpus() < args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but only {shard.visible_gpus()} GPU(s) are visible")
+    rank, world = shard.init(args.backend)    # nccl == RCCL on ROCm; no-op for one rank
     local_rank = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -131,7 +120,6 @@ def main():
     kind = int(w["kind"]) if "kind" in w.files else 0
     dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (kind,)
     obs_dim, A, S_dim, H, L = dims[:5]
-    kernel_name = search_kernel_name(obs_dim, A, S_dim, H, L, kind, args.sims)
     model_name = "LSTM" if kind == 1 else "MLP"
     G, S = args.games, args.sims
 
@@ -140,9 +128,11 @@ def main():
     dirichlet, noise = rng.noise_streams(seeds, A, S, 0.25, True)
     eng = SearchEngine(dims, G, S, discount=0.997, device=local_rank)
     eng.set_weights(w["blob"])
+    kernel_name = eng.search_kernel_name(S)          # from the library's own dispatch
     obs_d = torch.as_tensor(obs).to(dev)
     dir_d = torch.as_tensor(dirichlet).to(dev)
     noise_d = torch.as_tensor(noise).to(dev)
+    seeds_d = torch.as_tensor(seeds).to(dev)
     pack_h = torch.zeros(G * (A + 1), dtype=torch.int32).pin_memory()   # visits [G,A] | root values [G]
     visits_h = pack_h[: G * A].view(G, A)
     pack_d = eng.results_packed_view()
@@ -178,11 +168,30 @@ def main():
     elapsed = shard.max_over_ranks(time.perf_counter() - t0, dev)
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in zip(ev0, ev1)]))
+    # SURVEY.md 8(d) asks for the median over >= 20 batches next to the whole-region rate: start-to-start
+    # intervals of consecutive steps on the stream (kernel + the gap to the next launch)
+    step_ms = [ev0[i].elapsed_time(ev0[i + 1]) for i in range(args.steps - 1)]
+    step_ms_median = float(np.median(step_ms)) if step_ms else kernel_ms
     path_len = res["path_len"].cpu().numpy()
     assert int(visits_h.sum()) == G * S, "search did not complete every simulation"
     dbar = float(path_len.sum()) / (G * S)
     sims_per_step = world * G * S
     value = sims_per_step * args.steps / elapsed
+
+    # the same step with its random streams generated on the device first (a self-play move needs
+    # fresh streams: mzs_fill_streams + mzs_search), timed separately: never part of `value`
+    def step_streams():
+        d_, n_ = eng.fill_streams(seeds_d, S, True)
+        eng.search(obs_d, d_, n_, S, True)
+
+    for _ in range(min(args.warmup, 3)):
+        step_streams()
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step_streams()
+    fence()
+    elapsed_streams = shard.max_over_ranks(time.perf_counter() - t0, dev)
 
     out = {
         "metric": "MCTS sims/sec (whole node), CartPole MLP, 50 sims x 4096 games/GPU",
@@ -195,7 +204,12 @@ def main():
                                f"S_dim{S_dim} H{H} L{L}, {G} games/GPU x {S} sims, fused engine (1 launch per "
                                f"search, {'4 games' if 'quad' in kernel_name else '1 game'} per wavefront)",
                    "games_per_gpu": G, "num_simulations": S, "engine": "fused",
-                   "parallelism": f"games sharded over {world} GPU(s), no collective"},
+                   "parallelism": f"games sharded over {world} GPU(s), no collective",
+                   "world_size": dist.get_world_size() if world > 1 else 1,
+                   "backend": (dist.get_backend() if world > 1 else None)},
+        "value_median": world * G * S / (step_ms_median * 1e-3), "step_ms_median": step_ms_median,
+        "value_with_streams": sims_per_step * args.steps / elapsed_streams,
+        "ms_per_step_with_streams": 1e3 * elapsed_streams / args.steps,
     }
     if rank == 0:
         bps = algorithmic_bytes_per_sim(A, S_dim, dbar)

@@ -36,7 +36,6 @@ extern "C" {
 /* search engines */
 #define MZS_ENGINE_FUSED 0    /* one launch per search: wave per game, tree in LDS; picks the
                                  register-resident specialisation when the shape has one   */
-#define MZS_ENGINE_LOCKSTEP 1 /* select / inference / expand+backup kernels per simulation */
 #define MZS_ENGINE_FUSED_GENERIC 2 /* fused, always the runtime-shape kernel (A/B testing)  */
 
 typedef struct mzs_handle mzs_handle;
@@ -78,6 +77,12 @@ int mzs_search(mzs_handle* h, int32_t n_games, int32_t num_simulations, int32_t 
                const float* obs_dev, const double* dirichlet_dev, const double* noise_dev,
                int64_t noise_stride, void* stream);
 
+/* Name of the kernel mzs_search launches on this handle for a search of num_simulations
+ * simulations (the register-resident / weight-stream / generic variants, include the template
+ * arguments), NUL-terminated into name_out: what a profile of the search shows, for benchmark
+ * records.  No counterpart in the reference. */
+int mzs_search_kernel_name(mzs_handle* h, int32_t num_simulations, char* name_out, size_t name_size);
+
 /* The per-game random streams mzs_search consumes, generated on the device: for game g exactly
  * what numpy.random.RandomState(seeds[g]) returns for dirichlet([alpha] * A) (only when train and
  * num_simulations > 0) followed by uniform(lo, hi, size = mzs_max_draws(A, S)) — i.e. what the
@@ -99,15 +104,8 @@ int mzs_search_injected(mzs_handle* h, int32_t n_games, int32_t num_simulations,
                         const double* dirichlet_dev, const double* noise_dev,
                         int64_t noise_stride, void* stream);
 
-/* generate_action_and_policy_base_on_node_count (mcts.py:215-222) + what
- * Game.store_search_statistics reads (game.py:154-168).  Any pointer may be NULL.
- *   visits_dev     [n_games][A] i32  root-child visit counts
- *   root_value_dev [n_games] f32     root.value()
- *   root_prior_dev [n_games][A] f64  root-child priors after exploration noise
- *   consumed_dev   [n_games] i64     tie-break draws consumed (so the caller can advance its RNG)
- *   path_len_dev   [n_games] i64     total selections made (mean path length = /S) */
 /* Self-test of one assumption of the numeric contract on the device in use: the search kernels
- * take 1 / visit_count in f64 as hardware estimate + one Newton step, which must equal the
+ * take 1 / visit_count in f64 as hardware estimate + two Newton steps, which must equal the
  * correctly rounded quotient (what NumPy / the oracle compute) for every count a tree can hold.
  * Evaluates d = 1 .. n_max on the device and counts the mismatches against the host's 1.0 / d.
  * No counterpart in the reference (pb_c / (n + 1) is Python float division: mcts.py:158). */
@@ -122,6 +120,13 @@ int mzs_selftest_reciprocals(int32_t device, int32_t n_max, int32_t* n_bad);
  * No counterpart in the reference (its MCTS returns Python lists: mcts.py:215-222). */
 int mzs_set_result_sink(mzs_handle* h, int32_t* visits, float* root_value);
 
+/* generate_action_and_policy_base_on_node_count (mcts.py:215-222) + what
+ * Game.store_search_statistics reads (game.py:154-168).  Any pointer may be NULL.
+ *   visits_dev     [n_games][A] i32  root-child visit counts
+ *   root_value_dev [n_games] f32     root.value()
+ *   root_prior_dev [n_games][A] f64  root-child priors after exploration noise
+ *   consumed_dev   [n_games] i64     tie-break draws consumed (so the caller can advance its RNG)
+ *   path_len_dev   [n_games] i64     total selections made (mean path length = /S) */
 int mzs_results(mzs_handle* h, int32_t n_games, int32_t* visits_dev, float* root_value_dev,
                 double* root_prior_dev, int64_t* consumed_dev, int64_t* path_len_dev,
                 void* stream);

@@ -11,7 +11,6 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MZS_LIB") or os.path.join(_HERE, "libmzsearch.so")
 
 ENGINE_FUSED = 0
-ENGINE_LOCKSTEP = 1
 ENGINE_FUSED_GENERIC = 2
 OPT_ADAM, OPT_SGD = 0, 1
 
@@ -53,6 +52,7 @@ _SIGNATURES = {
     "mzs_set_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mzs_search": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
                              C.c_void_p, C.c_int64, C.c_void_p]),
+    "mzs_search_kernel_name": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t]),
     "mzs_fill_streams": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_double,
                                    C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "mzs_search_injected": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,

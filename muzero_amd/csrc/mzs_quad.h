@@ -533,7 +533,7 @@ __device__ __forceinline__ void quad_argmax_step(double& bs, int& ba, unsigned& 
     rew = take ? orw : rew;
 }
 
-/* RN(1 / d) in f64 for a visit count d: hardware estimate + one Newton step instead of a second
+/* RN(1 / d) in f64 for a visit count d: hardware estimate + two Newton steps instead of a second
  * dependent LDS read per tree level (the table lookup needs the child's record first).  Equal
  * to the correctly rounded quotient for every 1 <= d <= 65536 — all the counts a tree of at most
  * 65 535 nodes can hold — which mzs_selftest_reciprocals checks on the device in use

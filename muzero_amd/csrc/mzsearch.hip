@@ -1244,6 +1244,63 @@ int launch_quad(quad_kernel_t kernel, const SearchParams& p, const QuadLayout& q
     return MZS_OK;
 }
 
+/* what mzs_search launches for a search of S simulations on this handle: the one place the
+ * dispatch lives (mzs_search and mzs_search_kernel_name both read it) */
+enum { kPlanGeneric = 0, kPlanQuad = 1, kPlanStream = 2 };
+struct SearchPlan {
+    int kind;
+    quad_kernel_t kernel;
+    QuadLayout ql;
+    int wpb;
+    char name[96];
+};
+
+SearchPlan plan_search(const mzs_handle* h, int S) {
+    SearchPlan pl;
+    std::memset(&pl, 0, sizeof pl);
+    const mzs_dims& d = h->cfg.dims;
+    const int A = d.n_actions, n_nodes = mzs_nodes_per_game(A, S);
+    pl.kind = kPlanGeneric;
+    std::snprintf(pl.name, sizeof pl.name, "k_search_fused<false>");
+    if (h->cfg.engine != MZS_ENGINE_FUSED || mzs_max_draws(A, S) >= (1ll << 31)) return pl;
+    if (quad_kernel_t qk = pick_quad_kernel(d)) {
+        /* sixteen games per CU with their hidden states in LDS if that fits; else the variant
+         * with the hidden states in the global array, if it seats more waves per block */
+        const QuadLayout ql = make_quad_layout(A, n_nodes, S, true);
+        const int wpb = quad_waves_per_block(ql);
+        const QuadLayout qg = make_quad_layout(A, n_nodes, S, true, false);
+        const int wpg = wpb < 4 ? quad_waves_per_block(qg) : 0;
+        const bool hid_global = wpg > wpb;
+        if (hid_global || wpb > 0) {
+            pl.kind = kPlanQuad;
+            pl.kernel = hid_global ? pick_quad_kernel(d, true) : qk;
+            pl.ql = hid_global ? qg : ql;
+            pl.wpb = hid_global ? wpg : wpb;
+            std::snprintf(pl.name, sizeof pl.name, "k_search_quad<%d,%d,%d,false,%s,%s>", d.state_dim, A,
+                          d.hidden_dim, d.n_mid_layers ? "true" : "false", hid_global ? "true" : "false");
+            return pl;
+        }
+    }
+    quad_kernel_t wide = pick_quadw_kernel(d);
+    const bool lstm = !wide;
+    if (!wide) wide = pick_quadl_kernel(d);
+    if (wide && h->stream_plan.n > 0) { /* n == 0: more chunks per simulation than kMaxImages */
+        const int tab_floats = d.model_kind == MZS_MODEL_LSTM ? 4 * kLstmHeadTabFloats + 2 * A * 64
+                                                              : kWideTabFloats + A * 128;
+        const QuadLayout ql = make_quadw_layout(n_nodes, S, tab_floats);
+        const int wpb = quad_waves_per_block(ql);
+        if (wpb > 0) {
+            pl.kind = kPlanStream;
+            pl.kernel = wide;
+            pl.ql = ql;
+            pl.wpb = wpb;
+            std::snprintf(pl.name, sizeof pl.name, "k_search_quad%s<%d,%d,%d>", lstm ? "l" : "w", d.state_dim, A,
+                          d.hidden_dim);
+        }
+    }
+    return pl;
+}
+
 int check_search_args(mzs_handle* h, int n_games, int S, int train, const double* dirichlet,
                       const double* noise, int64_t stride) {
     if (!h) return fail(MZS_E_ARG, "null handle");
@@ -1478,38 +1535,27 @@ int mzs_search(mzs_handle* h, int32_t n_games, int32_t S, int32_t train, const f
     SearchParams p;
     fill_search_params(h, &p, n_games, S, train, dirichlet_dev, noise_dev, noise_stride);
     p.obs = obs_dev;
-    if (h->cfg.engine == MZS_ENGINE_FUSED && mzs_max_draws(h->cfg.dims.n_actions, S) < (1ll << 31)) {
-        if (quad_kernel_t qk = pick_quad_kernel(h->cfg.dims)) {
-            /* sixteen games per CU with their hidden states in LDS if that fits; else the variant
-             * with the hidden states in the global array, if it seats more waves per block */
-            const QuadLayout ql = make_quad_layout(p.m.A, p.n_nodes, S, true);
-            const int wpb = quad_waves_per_block(ql);
-            const QuadLayout qg = make_quad_layout(p.m.A, p.n_nodes, S, true, false);
-            const int wpg = wpb < 4 ? quad_waves_per_block(qg) : 0;
-            if (wpg > wpb)
-                return launch_quad(pick_quad_kernel(h->cfg.dims, true), p, qg, wpg, static_cast<hipStream_t>(stream));
-            if (wpb > 0) return launch_quad(qk, p, ql, wpb, static_cast<hipStream_t>(stream));
-        }
-        quad_kernel_t wide = pick_quadw_kernel(h->cfg.dims);
-        if (!wide) wide = pick_quadl_kernel(h->cfg.dims);
-        if (wide && h->stream_plan.n > 0) { /* n == 0: more chunks per simulation than kMaxImages */
-            const int A = h->cfg.dims.n_actions;
-            const int tab_floats = h->cfg.dims.model_kind == MZS_MODEL_LSTM ? 4 * kLstmHeadTabFloats + 2 * A * 64
-                                                                            : kWideTabFloats + A * 128;
-            const QuadLayout ql = make_quadw_layout(p.n_nodes, S, tab_floats);
-            const int wpb = quad_waves_per_block(ql);
-            if (wpb > 0) {
-                hipLaunchKernelGGL(k_build_stream, dim3(h->stream_plan.n), dim3(256), 0,
-                                   static_cast<hipStream_t>(stream), h->w_dev, h->stream_plan, h->stream_dev);
-                HIP_TRY(hipGetLastError());
-                p.img = h->stream_dev;
-                p.n_img = h->stream_plan.n;
-                p.first_img = h->stream_plan.first;
-                return launch_quad(wide, p, ql, wpb, static_cast<hipStream_t>(stream));
-            }
-        }
+    const SearchPlan plan = plan_search(h, S);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (plan.kind == kPlanGeneric) return launch(k_search_fused<false>, p, n_games, p.lds, st);
+    if (plan.kind == kPlanStream) {
+        hipLaunchKernelGGL(k_build_stream, dim3(h->stream_plan.n), dim3(256), 0, st, h->w_dev, h->stream_plan,
+                           h->stream_dev);
+        HIP_TRY(hipGetLastError());
+        p.img = h->stream_dev;
+        p.n_img = h->stream_plan.n;
+        p.first_img = h->stream_plan.first;
     }
-    return launch(k_search_fused<false>, p, n_games, p.lds, static_cast<hipStream_t>(stream));
+    return launch_quad(plan.kernel, p, plan.ql, plan.wpb, st);
+}
+
+int mzs_search_kernel_name(mzs_handle* h, int32_t num_simulations, char* name_out, size_t name_size) {
+    if (!h || !name_out || name_size == 0) return fail(MZS_E_ARG, "null argument");
+    if (num_simulations < 0 || num_simulations > h->cfg.max_simulations)
+        return fail(MZS_E_ARG, "num_simulations exceeds max_simulations of the handle");
+    const SearchPlan plan = plan_search(h, num_simulations);
+    std::snprintf(name_out, name_size, "%s", plan.name);
+    return MZS_OK;
 }
 
 int mzs_search_injected(mzs_handle* h, int32_t n_games, int32_t S, int32_t train,

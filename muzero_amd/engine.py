@@ -59,6 +59,7 @@ class SearchEngine:
         self.h = h
         self.n_games = 0
         self.num_simulations = 0
+        self.has_weights = False
 
     def close(self):
         if getattr(self, "h", None):
@@ -83,6 +84,7 @@ class SearchEngine:
             t = np.ascontiguousarray(blob, dtype=np.float32)
             ptr, n = t.ctypes.data_as(C.c_void_p), t.size
         _lib.check(self.lib.mzs_set_weights(self.h, ptr, n), "mzs_set_weights")
+        self.has_weights = True
 
     # ------------------------------------------------------------------- search
     def _stream(self):
@@ -113,6 +115,13 @@ class SearchEngine:
                                        _ptr(obs), _ptr(dirichlet), _ptr(noise), stride,
                                        self._stream()), "mzs_search")
         self.n_games, self.num_simulations = G, int(num_simulations)
+
+    def search_kernel_name(self, num_simulations=None):
+        """The kernel mzs_search dispatches to for this handle (mzs_search_kernel_name)."""
+        S = self.max_simulations if num_simulations is None else int(num_simulations)
+        buf = C.create_string_buffer(128)
+        _lib.check(self.lib.mzs_search_kernel_name(self.h, S, buf, 128), "mzs_search_kernel_name")
+        return buf.value.decode()
 
     def fill_streams(self, seeds, num_simulations, train=True, lo=1e-7, hi=2e-7):
         """Per-game streams generated on the device (mzs_fill_streams): returns device tensors

@@ -8,8 +8,9 @@ arguments (muzero_model.py:16-35), the attributes self_play.py / muzero_cli.py r
 `hidden_layer_dimension`, `number_of_hidden_layer`) and the three inference methods
 with their return types (muzero_model.py:828-905).
 
-Only `model_structure="mlp_model"` (neural_network_mlp_model.py) is implemented.
-Weights live in one packed fp32 blob (include/mzs_layout.h).
+`model_structure` "mlp_model" (neural_network_mlp_model.py) and "lstm_model"
+(neural_network_lstm_model.py) have kernels.  Weights live in one packed fp32 blob
+(include/mzs_layout.h).
 """
 import json
 import os
@@ -157,6 +158,7 @@ class Muzero:
         self._engine = None
         self._trainer = None
         self._blob = None
+        self._blob_stale = False
         self.weights_version = 0
         if not load:
             self.observation_dimension = _space_size(observation_space_dimensions)
@@ -196,18 +198,34 @@ class Muzero:
         if blob.size != n:
             raise ValueError(f"weight blob has {blob.size} floats, expected {n}")
         self._blob = blob
+        self._blob_stale = False
         self.weights_version += 1
         if self._engine is not None:
             self._engine.set_weights(blob)
 
     def weights_blob(self):
+        """The packed blob, fetched from the device first if training steps ran since the last copy
+        (note_trained marks it stale instead of copying 51 KB back after every step)."""
+        if self._blob_stale and self._trainer is not None:
+            self._blob = self._trainer.weights()
+            self._blob_stale = False
         return self._blob
 
+    def note_trained(self, trainer, loss=None):
+        """Bookkeeping after a training step that went through `trainer` directly (SelfPlay.train_step):
+        what Muzero.train does after its own steps (muzero_model.py:786-789)."""
+        self.count = trainer.count
+        self._blob_stale = True
+        self.weights_version += 1
+        if loss is not None:
+            loss = np.asarray(loss, np.float32)
+            self.store_loss.append([torch.tensor(loss[-1])] + [torch.tensor(x) for x in loss[:-1]])
+
     def named_weights(self):
-        out, p = {}, 0
+        out, p, blob = {}, 0, self.weights_blob()
         for name, shape in blob_layout(*self.dims):
             n = int(np.prod(shape))
-            out[name] = self._blob[p:p + n].reshape(shape)
+            out[name] = blob[p:p + n].reshape(shape)
             p += n
         return out
 
@@ -222,7 +240,7 @@ class Muzero:
     def _inference_engine(self):
         if self._engine is None:
             self._engine = SearchEngine(self.dims, max_games=1, max_simulations=0)
-            self._engine.set_weights(self._blob)
+            self._engine.set_weights(self.weights_blob())
         return self._engine
 
     @staticmethod
@@ -272,18 +290,14 @@ class Muzero:
         obs, actions, tv, trw, tp, ratio, game_pos = tr.reshape_batch(
             batch, self.observation_dimension, self.action_dimension, self.k_hypothetical_steps)
         B = obs.shape[0]
-        if self._trainer is None or self._trainer.max_batch < B:
-            if self._trainer is not None:       # a bigger batch: new handle, keep step count / weights
-                self._blob = self._trainer.weights()
-                self._engine = None
-            eng = self._inference_engine()
-            old = self._trainer
-            self._trainer = tr.Trainer(eng, self.k_hypothetical_steps, B, self.opt, self.lr, self.sch,
-                                       self.epoch)
-            if old is not None:
-                raise NotImplementedError("growing the batch size after the first train() call would "
-                                          "drop the optimizer state; create the model with the "
-                                          "largest batch first")
+        if self._trainer is not None and self._trainer.max_batch < B:
+            # refuse BEFORE touching any state: a retry must not succeed on a fresh optimizer
+            raise NotImplementedError(f"batch of {B} after a first train() call with {self._trainer.max_batch}: "
+                                      "growing the batch would drop the optimizer state; create the "
+                                      "model with the largest batch first")
+        if self._trainer is None:
+            self._trainer = tr.Trainer(self._inference_engine(), self.k_hypothetical_steps, B, self.opt, self.lr,
+                                       self.sch, self.epoch)
         t = self._trainer
         t.count = self.count
         prio = t.step(obs, actions, tv, trw, tp, ratio)
@@ -291,7 +305,7 @@ class Muzero:
         torch.cuda.synchronize(t.eng.device)
         loss = t.loss.cpu().numpy()
         self.store_loss.append([torch.tensor(loss[-1])] + [torch.tensor(x) for x in loss[:-1]])
-        self._blob = t.weights()
+        self._blob_stale = True
         self.weights_version += 1
         prio = prio.cpu().numpy()
         return [prio[k].reshape(-1, 1) for k in range(prio.shape[0])], game_pos
@@ -317,7 +331,7 @@ class Muzero:
         os.makedirs(directory, exist_ok=True)
         if tag:
             self.random_tag = tag
-        np.savez(f"{directory}/{self.random_tag}_muzero_weights.npz", blob=self._blob)
+        np.savez(f"{directory}/{self.random_tag}_muzero_weights.npz", blob=self.weights_blob())
         with open(f"{directory}/{self.random_tag}_muzero_init_variables.json", "w") as f:
             json.dump(self._init_variables(), f)
 

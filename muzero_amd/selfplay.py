@@ -239,7 +239,8 @@ class ReplayStore:
             if self.uses_priority:
                 if g not in cache:      # soft_prio_position (replay_buffer.py:102) and its cdf, once per game
                     p = pp[g]
-                    soft = p / p.sum()
+                    with np.errstate(invalid="ignore", divide="ignore"):   # an all-zero row -> NaN, rejected below as the reference's np.random.choice does
+                        soft = p / p.sum()
                     cdf = None
                     if prio_pos:
                         if not np.isfinite(soft[-1]) or soft.min() < 0:     # what RandomState.choice rejects
@@ -484,6 +485,10 @@ class SelfPlay:
         trainer = Trainer(eng, m["k_hypothetical_steps"], rb["batch_size"], m["optimizer"], m["learning_rate"],
                           m["lr_scheduler"], m["num_of_epoch"])
         mz._trainer = trainer
+        from .shard import rank_world
+        if rank_world()[1] > 1:      # Trainer broadcast rank 0's weights into the handle: mz follows
+            mz._blob_stale = True
+            mz.weights_version += 1
         store = ReplayStore(W, rb["batch_size"], m["k_hypothetical_steps"], rb["td_steps"], rb["game_sampling"],
                             rb["position_sampling"], discount=gp["discount"])
         n_blocks = -(-(W + 1) // N) + 1
@@ -492,11 +497,13 @@ class SelfPlay:
         loop.cfg = cfg
         return loop
 
-    def run_config(self, number_of_iteration=None, verbose=False):
+    def run_config(self, number_of_iteration=None, verbose=False, model_tag_number=None,
+                   checkpoint_directory="model_checkpoint"):
         """learning_cycle with the config's own iteration counts and temperature schedule."""
         lc = self.cfg["learning_cycle"]
         return self.learning_cycle(int(number_of_iteration or lc["number_of_iteration"]),
-                                   lc["number_of_training_before_self_play"], lc["tempererature_type"], verbose)
+                                   lc["number_of_training_before_self_play"], lc["tempererature_type"], verbose,
+                                   model_tag_number=model_tag_number, checkpoint_directory=checkpoint_directory)
 
     def play(self, temperature):
         """One round of N games into the next block of rows; returns their total rewards."""
@@ -524,17 +531,28 @@ class SelfPlay:
         obs, actions, tv, tr, tp = self.arena.make_batch(row_pos, st.num_unroll, st.td_steps, st.discount)
         isr = None if np.size(ratio) == 1 else np.asarray(ratio, np.float32)
         prio = self.trainer.step(obs, actions, tv, tr, tp, isr)
-        loss = self.trainer.loss[-1].clone()        # loss_nn (muzero_model.py:734), still on the device
+        loss = self.trainer.loss.clone()            # the 3K-1 terms then loss_nn (muzero_model.py:734), on the device
         if st.uses_priority:
             st.update_value(prio.detach().cpu().numpy(), game_pos)
-        return loss
+        if self.mz is not None:
+            # keep the drop-in model object in step with the trainer it shares a handle with: step
+            # count (lr schedule), store_loss, and a weight blob that save_model / a later
+            # Monte_carlo_tree_search.run(model=mz) will fetch from the device
+            self.mz.note_trained(self.trainer, loss.cpu().numpy())
+        return loss[-1]
 
     def learning_cycle(self, number_of_iteration, number_of_training_before_self_play=1,
-                       temperature_type="static_temperature", verbose=False):
+                       temperature_type="static_temperature", verbose=False, model_tag_number=None,
+                       checkpoint_directory="model_checkpoint"):
+        """model_tag_number: as the reference (self_play.py:248-255), the model is saved whenever an
+        iteration's mean self-play reward is the best so far; None (default) writes nothing."""
         rewards, losses = [], []
         for ep in range(1, number_of_iteration + 1):
             t = temperature_scheduler(number_of_iteration + 1, ep, temperature_type)
             rewards.append(float(np.mean(self.play(t))))
+            if self.mz is not None and model_tag_number is not None:
+                self.mz.save_model(directory=checkpoint_directory, tag=model_tag_number,
+                                   model_update_condition=bool(rewards[-1] == max(rewards)))
             cache = [self.train_step() for _ in range(number_of_training_before_self_play)]
             losses.append(float(torch.stack(cache).mean().item()))
             if verbose:

@@ -9,8 +9,10 @@ weight gradients, optimizer.
 Data parallelism: one process per GPU; every rank runs `mzs_train_grad` on its shard of the
 batch with `inv_global_batch = 1 / global batch size`, the flat fp32 gradient (12 734 floats
 for the CartPole MLP) is summed with ONE `all_reduce` (RCCL over xGMI under the "nccl"
-backend, gloo in the CPU tests) and every rank applies the same optimizer step, so the
-replicas stay bit-identical without a weight broadcast.
+backend, gloo in the CPU tests) and every rank applies the same optimizer step, so replicas
+that start identical stay bit-identical.  They start identical because Trainer broadcasts rank
+0's weights once at construction (every process draws its initial weights from its own torch
+generator; shard.broadcast_blob).
 """
 import ctypes as C
 import math
@@ -99,6 +101,17 @@ class Trainer:
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.loss = torch.zeros(3 * self.K, dtype=torch.float32, device=dev)
         self.priority = torch.zeros((self.K, self.max_batch), dtype=torch.float32, device=dev)
+        self.sync_replicas()
+
+    def sync_replicas(self):
+        """One broadcast of rank 0's weights (no-op for one rank): the all-reduced gradient step
+        keeps replicas identical only from an identical start."""
+        import torch.distributed as dist
+        if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+                and self.eng.has_weights):
+            from . import shard
+            dev = self.eng.device if dist.get_backend() == "nccl" else None
+            self.eng.set_weights(shard.broadcast_blob(self.weights(), dev))
 
     def current_lr(self):
         return scheduled_lr(self.sch, self.lr, self.epoch, self.count)

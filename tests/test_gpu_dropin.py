@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from conftest import fixture_weights, load_golden
-from test_oracle_golden import MARGIN_TAU, REL, hidden_err, rel_err, value_err
+from test_oracle_golden import REL, hidden_err, rel_err, value_err
 
 pytestmark = pytest.mark.gpu
 
@@ -51,13 +51,11 @@ def test_run_is_drop_in(fname, tag, n):
             assert rel_err(policy, fx["visits"][g]).max() < REL     # priors as float64
             assert root.visit_count == 0 and root.value() == 0
             continue
-        if fx["min_margin"][g] < MARGIN_TAU:
-            continue
-        assert np.array_equal(policy, fx["visits"][g])
+        assert np.array_equal(policy, fx["visits"][g])          # every search, near-ties included
         # what Game.store_search_statistics reads (game.py:154-168)
         vc = np.array([c.visit_count for c in root.children.values()], dtype=np.float64)
         assert np.array_equal(vc, fx["visits"][g]) and vc.sum() == S
-        assert value_err(root.value(), fx["root_value"][g]) <= 1
+        assert rel_err(root.value(), fx["root_value"][g]) < REL      # S >= 11: plain 1e-5
         assert isinstance(root.value(), np.floating)
         pri = [root.children[a].prior for a in range(A)]
         assert rel_err(pri, fx["root_prior"][g]).max() < REL

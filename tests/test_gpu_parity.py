@@ -11,7 +11,8 @@ import numpy as np
 import pytest
 
 from conftest import (MODEL_TAGS, SEARCH_FIXTURES, fixture_streams, fixture_weights, load_golden)
-from test_oracle_golden import MARGIN_TAU, REL, hidden_err, leaves_of, rel_err, table_of, value_err
+from test_oracle_golden import (REL, check_L3_against_reference, hidden_err, leaves_of, rel_err, table_of,
+                                value_err)
 
 pytestmark = pytest.mark.gpu
 
@@ -99,7 +100,8 @@ def test_L2_inference_kernels(tag):
 @pytest.mark.parametrize("fname,tag", SEARCH_FIXTURES)
 def test_L3_search_end_to_end(fname, tag, engine):
     """Full search on the GPU: bit-exact vs the oracle on every game; vs the reference,
-    identical visit counts on every search without a near-tie."""
+    identical visit counts on EVERY search (near-ties included; counts pinned in
+    tests/golden/parity_table.json) and root values within a plain 1e-5 relative."""
     from oracle import mz_oracle as mzo
     fx = load_golden(fname)
     d, blob = fixture_weights(tag)
@@ -132,12 +134,10 @@ def test_L3_search_end_to_end(fname, tag, engine):
     # against the reference run itself
     assert rel_err(out["root_prior"], fx["root_prior"]).max() < REL
     if S > 0:
-        same = np.all(out["visits"].astype(np.float64) == fx["visits"], axis=1)
-        safe = fx["min_margin"] >= MARGIN_TAU
-        assert np.all(same[safe])
-        assert value_err(out["root_value"][same], fx["root_value"][same]).max() <= 1
-        t0 = np.argmax(out["visits"], axis=1)
-        assert np.array_equal(t0[same], fx["t0_action"][same])
+        m = check_L3_against_reference(fname, fx, out["visits"], out["root_value"])
+        print(f"\n{fname} [{engine}]: visit counts identical {m['matched']}/{m['searches']} (near-ties "
+              f"{m['near_ties']}), root value max rel err {m['root_value_rel']:.2e}")
+        assert np.array_equal(np.argmax(out["visits"], axis=1), fx["t0_action"])
     eng.close()
 
 
@@ -376,7 +376,7 @@ def test_result_sink_matches_device_results(tag):
 
 
 def test_device_reciprocals_are_correctly_rounded():
-    """quad_rcp_count (hardware rcp + one Newton step, f64) == 1.0 / d for every visit count a tree
+    """quad_rcp_count (hardware rcp + two Newton steps, f64) == 1.0 / d for every visit count a tree
     can hold (d <= 65536): the one place where the search kernels do not take a quotient from
     IEEE division or a host-made table."""
     import ctypes as C

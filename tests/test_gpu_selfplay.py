@@ -243,9 +243,29 @@ def test_learning_cycle_from_reference_config(tmp_path):
     np.random.seed(1)
     loop = SelfPlay.from_config(load_config(str(path)), n_slots=256, games_per_iteration=600, window_size=1500)
     assert loop.arena.G == 256 and loop.arena.T == 500 and loop.S == 11 and loop.store.td_steps == 50
-    rewards, losses = loop.run_config(number_of_iteration=3)
+    mz = loop.mz
+    w0 = mz.weights_blob().copy()
+    rewards, losses = loop.run_config(number_of_iteration=3, model_tag_number=777,
+                                      checkpoint_directory=str(tmp_path / "ckpt"))
     assert len(rewards) == 3 and all(np.isfinite(losses)) and len(loop.store) == 1501
     assert loop.trainer.count == 3
+    # the drop-in model object follows the trainer it shares a handle with: step count,
+    # store_loss, and the weights save_model / a later Monte_carlo_tree_search.run(model=mz) see
+    assert mz.count == 3 and len(mz.store_loss) == 3 and len(mz.store_loss[-1]) == 3 * 10
+    assert abs(float(mz.store_loss[-1][0]) - losses[-1]) <= 1e-6 * abs(losses[-1])
+    trained = loop.trainer.weights()
+    assert not np.array_equal(trained, w0) and np.array_equal(mz.weights_blob(), trained)
+    # the best-reward checkpoint was written before that iteration's training step (self_play.py:248-262)
+    assert (tmp_path / "ckpt" / "777_muzero_init_variables.json").exists()
+    mz.save_model(directory=str(tmp_path / "final"), tag=778, model_update_condition=True)
+    assert np.array_equal(np.load(tmp_path / "final" / "778_muzero_weights.npz")["blob"], trained)
+    from muzero_amd.model import Muzero
+    back = Muzero(load=True)
+    back.load_model(str(tmp_path / "final"), tag=778)
+    assert np.array_equal(back.weights_blob(), trained) and back.dims == mz.dims
+    # Muzero.train after the loop continues the schedule instead of rewinding it
+    row_pos, ratio, game_pos = loop.store.sample_batch()
+    assert mz._trainer is loop.trainer and mz._trainer.count == 3
     loop.arena.close(), loop.eng.close()
 
 

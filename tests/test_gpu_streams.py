@@ -25,8 +25,11 @@ def test_streams_equal_randomstate(A, S, train):
     if train and S > 0:
         d = dirichlet.cpu().numpy()
         # legacy gamma sampler through the device's fp64 log / pow: same accept/reject path
-        # (else the uniforms above would be shifted), values within a few ulp
-        assert np.abs(d - ref_d).max() <= 1e-14
+        # (else the uniforms above would be shifted); every component within a few ulp OF ITSELF
+        # (pow and log are each good to an ulp or two, the normalisation adds the sum's error)
+        ulps = np.abs(d - ref_d) / np.spacing(np.abs(ref_d))
+        print(f"\nDirichlet A={A} S={S}: max error {ulps.max():.1f} ulp")
+        assert ulps.max() <= 8
         assert np.allclose(d.sum(axis=1), 1.0, atol=1e-15)
     else:
         assert dirichlet is None

@@ -9,8 +9,35 @@ import pytest
 from conftest import (MODEL_TAGS, SEARCH_FIXTURES, fixture_streams, fixture_weights, load_golden)
 from oracle import mz_oracle as mzo
 
+import json
+import os
+
 REL = 1e-5          # north_star: root values and policies within 1e-5 relative (fp32)
-MARGIN_TAU = 1e-4   # L3: decisions closer than this may flip under the model tolerance
+MARGIN_TAU = 1e-4   # decisions closer than this count as near-ties in the printed summary
+
+with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "parity_table.json")) as _f:
+    PARITY_TABLE = json.load(_f)
+
+
+def check_L3_against_reference(fname, fx, visits, root_value):
+    """The L3 bar shared by the CPU (oracle) and GPU tests: EVERY search of the fixture reproduces
+    the reference's visit counts (near-ties included: the count per file is pinned in
+    tests/golden/parity_table.json, so one flipped search fails), and root values are within a plain
+    1e-5 relative of the reference's, no grid allowance — except the S = 1 fixture, whose root value
+    IS a single leaf scalar (root.value() = the one backed-up value) and carries value_err's grid
+    step like every other single-leaf scalar.  Returns the measured maxima for the test's printout."""
+    row = PARITY_TABLE[fname]
+    same = np.all(np.asarray(visits).astype(np.float64) == fx["visits"], axis=1)
+    assert len(same) == row["searches"]
+    assert int(same.sum()) == row["visits_equal"], f"{fname}: {int(same.sum())}/{len(same)} searches match"
+    rv = rel_err(root_value, fx["root_value"]).max()
+    if row.get("single_leaf"):
+        assert value_err(root_value, fx["root_value"]).max() <= 1
+    else:
+        assert rv < REL, f"{fname}: root value rel err {rv:.3e}"
+    assert rv <= row["root_value_rel_max"], f"{fname}: root value rel err {rv:.3e} above the pinned bound"
+    near = int((fx["min_margin"] < MARGIN_TAU).sum())
+    return dict(matched=int(same.sum()), searches=len(same), near_ties=near, root_value_rel=float(rv))
 
 
 def rel_err(a, b):
@@ -21,6 +48,12 @@ def rel_err(a, b):
 
 def value_err(a, b):
     """Error of a value/reward scalar in units of its tolerance (<= 1 passes).
+
+    Used for SINGLE-LEAF scalars only (a value / reward straight out of one inverse transform);
+    root values of searches with S >= 11 are held to a plain 1e-5 (check_L3_against_reference).
+    Measured maxima on the fixtures (oracle == GPU bits): value 7.96e-5 rel (tag123), 7.1e-5
+    (tag127), 2.0e-5 (tag133), reward 3.9e-5 (synA3) — each exactly one grid step — policies
+    <= 4.8e-6, hidden states <= 1.0e-6 absolute.
 
     inverse_transform_with_support (muzero_model.py:585-586) evaluates
     ((sqrt(1 + 0.004(|y|+1.001)) - 1)/0.002)^2 - 1 in fp32: sqrt(t) lies in [1, 2)
@@ -137,15 +170,9 @@ def test_L3_search_end_to_end(fname, tag):
     assert rel_err(out["root_prior"], fx["root_prior"]).max() < REL
     if S == 0:
         return
-    same = np.all(out["visits"].astype(np.float64) == fx["visits"], axis=1)
-    safe = fx["min_margin"] >= MARGIN_TAU
-    # every search without a near-tie must reproduce the reference's visit counts exactly
-    assert np.all(same[safe]), f"{(~same[safe]).sum()} safe searches differ"
-    # the root value is a mean of backed-up values that each sit on the q(v) grid
-    assert value_err(out["root_value"][same], fx["root_value"][same]).max() <= 1
-    print(f" root value max rel err {rel_err(out['root_value'][same], fx['root_value'][same]).max():.2e}", end="")
-    print(f"\n{fname}: visit counts identical {same.sum()}/{len(same)} "
-          f"(safe {safe.sum()}, near-tie {len(same) - safe.sum()})")
+    m = check_L3_against_reference(fname, fx, out["visits"], out["root_value"])
+    print(f"\n{fname}: visit counts identical {m['matched']}/{m['searches']} (of which near-ties "
+          f"{m['near_ties']}), root value max rel err {m['root_value_rel']:.2e}")
 
 
 def test_oracle_threads_agree():

@@ -3,13 +3,23 @@ data-path collective; the union of the per-rank results equals one single-rank r
 all games.  The per-rank compute here is the CPU oracle (there is no GPU in this container);
 on the GPU box the same sharding code drives the HIP engine (bench.py)."""
 import os
-import socket
 import subprocess
 import sys
 
 import numpy as np
 
 from conftest import ROOT, fixture_weights
+
+
+def run_two_ranks(tmp_path, name, source, out):
+    """Start the worker through muzero_amd.shard.launch_ranks — the launcher `bench.py --gpus N`
+    and `tools/bench_train.py --gpus N` use (require_gpus=False: gloo ranks on CPU here)."""
+    from muzero_amd import shard
+    script = tmp_path / name
+    script.write_text(source)
+    rc = shard.launch_ranks(str(script), [], 2, require_gpus=False,
+                            extra_env=dict(MZ_ROOT=ROOT, MZ_OUT=out, OMP_NUM_THREADS="1"))
+    assert rc == 0, f"{name}: launcher exit code {rc}"
 
 WORKER = r'''
 import os, sys
@@ -39,16 +49,8 @@ dist.barrier(); dist.destroy_process_group()
 def test_two_ranks_equal_one(tmp_path):
     from muzero_amd import rng, shard
     from oracle import mz_oracle as mzo
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     out = str(tmp_path / "gathered.npz")
-    script = tmp_path / "worker.py"
-    script.write_text(WORKER)
-    env = dict(os.environ, MZ_ROOT=ROOT, MZ_OUT=out, OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-    subprocess.run(cmd, env=env, check=True, timeout=300, capture_output=True)
+    run_two_ranks(tmp_path, "worker.py", WORKER, out)
     got = np.load(out)
     # single-rank reference over the same 48 global games
     d, blob = fixture_weights("tag123")
@@ -95,16 +97,8 @@ def test_data_parallel_training_step_two_ranks(tmp_path):
     """Each rank: gradients of its half of the batch, ONE all-reduce of the flat bucket, the same
     optimizer step -> both replicas hold the weights of the single-rank step (= the reference's)."""
     from conftest import load_golden
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     out = str(tmp_path / "dp")
-    script = tmp_path / "train_worker.py"
-    script.write_text(TRAIN_WORKER)
-    env = dict(os.environ, MZ_ROOT=ROOT, MZ_OUT=out, OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-    subprocess.run(cmd, env=env, check=True, timeout=300, capture_output=True)
+    run_two_ranks(tmp_path, "train_worker.py", TRAIN_WORKER, out)
     r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
     assert np.array_equal(r0["blob"], r1["blob"]) and np.array_equal(r0["grad"], r1["grad"])
     fx = load_golden("train_tag123_K5_B128.npz")
@@ -147,16 +141,8 @@ def test_self_play_shards_by_game_seed(tmp_path):
     on its seed only).  CPU oracle arena stands in for the GPU arena (same arithmetic, bit-exact)."""
     from muzero_amd import selfplay
     from oracle import mz_oracle as mzo
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     out = str(tmp_path / "sp.npz")
-    script = tmp_path / "sp_worker.py"
-    script.write_text(SELFPLAY_WORKER)
-    env = dict(os.environ, MZ_ROOT=ROOT, MZ_OUT=out, OMP_NUM_THREADS="1")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), str(script)]
-    subprocess.run(cmd, env=env, check=True, timeout=300, capture_output=True)
+    run_two_ranks(tmp_path, "sp_worker.py", SELFPLAY_WORKER, out)
     got = np.load(out)
     N, G, T = 80, 7, 30          # one process, all 80 games, a different slot count on purpose
     seeds = (np.arange(N, dtype=np.int64) * 2654435761 + 5) & 0x7FFFFFFF
@@ -168,3 +154,50 @@ def test_self_play_shards_by_game_seed(tmp_path):
             break
     assert np.array_equal(got["lengths"], ar.length)
     assert int(got["big_n"]) == int(ar.length[:40].sum())
+
+
+BCAST_WORKER = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["MZ_ROOT"])
+from muzero_amd import shard
+import torch.distributed as dist
+rank, world = shard.init("gloo")
+torch.manual_seed(100 + rank)                      # what separate processes do: different initial weights
+blob = torch.normal(0.0, 1 / 137.035999, size=(12734,)).numpy()
+try:
+    shard.assert_replicas_identical(blob)
+    differ = False
+except RuntimeError:
+    differ = True
+synced = shard.broadcast_blob(blob)
+shard.assert_replicas_identical(synced)            # raises if the broadcast did not make them equal
+np.savez(os.environ["MZ_OUT"] + f".{rank}.npz", own=blob, synced=synced, differ=differ)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_initial_weights_are_broadcast(tmp_path):
+    """Every process draws its own initial weights (Muzero.initiate_model_weight uses torch's global
+    generator): Trainer.sync_replicas -> shard.broadcast_blob makes rank 0's the common start, and
+    assert_replicas_identical catches replicas that differ."""
+    out = str(tmp_path / "bc")
+    run_two_ranks(tmp_path, "bcast_worker.py", BCAST_WORKER, out)
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    assert bool(r0["differ"]) and bool(r1["differ"])
+    assert not np.array_equal(r0["own"], r1["own"])
+    assert np.array_equal(r0["synced"], r0["own"]) and np.array_equal(r1["synced"], r0["own"])
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus N` is how the driver asks for N ranks: with fewer GPUs visible it must
+    fail loudly instead of printing an n_gpus: 1 line (there is no GPU in the build container, so
+    N = 2 is already too many here; on the GPU box the visible count decides)."""
+    import torch
+    n = torch.cuda.device_count() + 1
+    for script in ("bench.py", os.path.join("tools", "bench_train.py")):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, script), "--gpus", str(max(n, 2))],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode != 0
+        assert "GPU(s) are visible" in r.stderr
+        assert '"n_gpus"' not in r.stdout
