@@ -194,6 +194,24 @@ int mzs_train_grad(mzs_handle* h, int32_t batch, const float* obs_dev, const flo
                    const float* target_policy_dev, const float* is_ratio_dev, float inv_global_batch,
                    float* grad_dev, float* loss_dev, float* priority_dev, void* stream);
 
+/* mzs_train_grad for callers that cannot allocate: code under HIP graph capture, tight serving /
+ * training loops, harnesses that forbid hipMalloc.  NO counterpart in the reference (its training
+ * step allocates autograd tensors freely).  Same arguments (plus unroll_steps, which mzs_train_grad
+ * takes from mzs_train_create), same kernels, same results bit for bit — but it needs no
+ * mzs_train_create and calls no hipMalloc / hipFree / allocating routine: tapes, per-sample loss
+ * terms and gradient partial sums live in a file-scope static device array of
+ * MZS_STATIC_SCRATCH_BYTES (16 MiB) that every GPU the library runs on holds until the process
+ * ends.  Sizes beyond it (e.g. the CartPole MLP at unroll 5 fits batch <= ~900) return MZS_E_ARG.
+ * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
+ * handles, two threads) race — serialise them.  The handle still comes from mzs_create +
+ * mzs_set_weights (which allocate, once, outside the loop). */
+#define MZS_STATIC_SCRATCH_BYTES (16u << 20)
+int mzs_train_grad_static(mzs_handle* h, int32_t batch, int32_t unroll_steps, const float* obs_dev,
+                          const float* actions_dev, const float* target_value_dev,
+                          const float* target_reward_dev, const float* target_policy_dev,
+                          const float* is_ratio_dev, float inv_global_batch, float* grad_dev, float* loss_dev,
+                          float* priority_dev, void* stream);
+
 /* optimizer.step() (muzero_model.py:764) with the (all-reduced) gradient; lr is the scheduler's
  * current value (muzero_amd/train.py evaluates the reference's schedulers on the host). */
 int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, double lr, void* stream);

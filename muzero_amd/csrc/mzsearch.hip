@@ -11,6 +11,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <string>
 #include <type_traits>
@@ -26,6 +27,13 @@
 #include "mzs_replay.h"
 
 using namespace mzs;
+
+/* Scratch of the no-allocation entry point (mzs_train_grad_static, include/mzsearch.h): one copy
+ * per GPU the library runs on, held until the process ends.  In host code this name is only a
+ * stand-in for the symbol: the device address comes from hipGetSymbolAddress, once per device
+ * (scratch_for_device below), and only that pointer is ever handed to kernels. */
+constexpr size_t kStaticScratchBytes = (size_t)MZS_STATIC_SCRATCH_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticScratchBytes];
 
 namespace {
 
@@ -44,6 +52,24 @@ int fail(int code, const std::string& msg) {
     } while (0)
 
 inline int round_up(int x, int m) { return (x + m - 1) / m * m; }
+
+/* device address of this GPU's copy of `scratch`; `device` must be the current device */
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+void* g_scratch_ptr[kMaxDevices] = {};
+
+int scratch_for_device(int device, void** out) {
+    if (device < 0 || device >= kMaxDevices) return fail(MZS_E_ARG, "device ordinal out of range");
+    std::lock_guard<std::mutex> lock(g_scratch_mu);
+    if (!g_scratch_ptr[device]) {
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        if (!p) return fail(MZS_E_HIP, "hipGetSymbolAddress(scratch) returned a null address");
+        g_scratch_ptr[device] = p;
+    }
+    *out = g_scratch_ptr[device];
+    return MZS_OK;
+}
 
 /* byte offsets inside one wave's LDS slice */
 struct LdsLayout {
@@ -1399,6 +1425,12 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     if (cfg->engine != MZS_ENGINE_FUSED && cfg->engine != MZS_ENGINE_FUSED_GENERIC)
         return fail(MZS_E_ARG, "unknown engine");
     HIP_TRY(hipSetDevice(cfg->device));
+    {
+        /* set-up for mzs_train_grad_static: this GPU's address of the static scratch array */
+        void* sp = nullptr;
+        const int rc = scratch_for_device(cfg->device, &sp);
+        if (rc) return rc;
+    }
     mzs_handle* h = new (std::nothrow) mzs_handle();
     if (!h) return fail(MZS_E_ARG, "out of host memory");
     h->cfg = *cfg;
@@ -1793,6 +1825,50 @@ int mzs_train_create(mzs_handle* h, int32_t max_batch, int32_t unroll_steps) {
     return MZS_OK;
 }
 
+/* the three launches of the gradient computation with the tape / loss / partial-sum buffers given */
+static int train_grad_launch(mzs_handle* h, const TapeLayout& tl, int K, int32_t batch, const float* obs_dev,
+                             const float* actions_dev, const float* target_value_dev, const float* target_reward_dev,
+                             const float* target_policy_dev, const float* is_ratio_dev, float inv_global_batch,
+                             float* grad_dev, float* loss_dev, float* priority_dev, float* tape, float* loss_buf,
+                             double* partial, hipStream_t st) {
+    TrainParams p;
+    std::memset(&p, 0, sizeof p);
+    p.m = h->model;
+    p.tl = tl;
+    fill_tensor_descs(h->cfg.dims, p.tl, K, p.td);
+    p.bo = mzs_blob_layout(&h->cfg.dims);
+    p.blob = h->blob_dev;
+    p.B = batch;
+    p.K = K;
+    p.n_params = (int)p.bo.total;
+    p.inv_batch = inv_global_batch;
+    p.obs = obs_dev;
+    p.actions = actions_dev;
+    p.tv = target_value_dev;
+    p.tr = target_reward_dev;
+    p.tp = target_policy_dev;
+    p.is_ratio = is_ratio_dev;
+    p.tape = tape;
+    p.loss_buf = loss_buf;
+    p.priority = priority_dev;
+    p.grad = grad_dev;
+    p.loss_out = loss_dev;
+    const size_t shmem = (size_t)p.tl.total * sizeof(float);
+    if (shmem > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_sample),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    hipLaunchKernelGGL(k_train_sample, dim3(batch), dim3(kWave), shmem, st, p);
+    HIP_TRY(hipGetLastError());
+    const int n_grad_blocks = (p.n_params + 255) / 256;
+    const int n_chunks = (batch + kWgradChunk - 1) / kWgradChunk;
+    hipLaunchKernelGGL(k_train_wgrad_partial, dim3(n_grad_blocks, n_chunks), dim3(256), 0, st, p, partial);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_train_wgrad, dim3(n_grad_blocks + 1), dim3(256), 0, st, p, (const double*)partial, n_chunks,
+                       n_grad_blocks);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
 int mzs_train_grad(mzs_handle* h, int32_t batch, const float* obs_dev, const float* actions_dev,
                    const float* target_value_dev, const float* target_reward_dev,
                    const float* target_policy_dev, const float* is_ratio_dev, float inv_global_batch,
@@ -1805,44 +1881,61 @@ int mzs_train_grad(mzs_handle* h, int32_t batch, const float* obs_dev, const flo
         !grad_dev || !loss_dev || !priority_dev)
         return fail(MZS_E_ARG, "null buffer");
     HIP_TRY(hipSetDevice(h->cfg.device));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    TrainParams p;
-    std::memset(&p, 0, sizeof p);
-    p.m = h->model;
-    p.tl = h->tape_layout;
-    fill_tensor_descs(h->cfg.dims, p.tl, h->train_K, p.td);
-    p.bo = mzs_blob_layout(&h->cfg.dims);
-    p.blob = h->blob_dev;
-    p.B = batch;
-    p.K = h->train_K;
-    p.n_params = (int)p.bo.total;
-    p.inv_batch = inv_global_batch;
-    p.obs = obs_dev;
-    p.actions = actions_dev;
-    p.tv = target_value_dev;
-    p.tr = target_reward_dev;
-    p.tp = target_policy_dev;
-    p.is_ratio = is_ratio_dev;
-    p.tape = h->tape_dev;
-    p.loss_buf = h->loss_buf_dev;
-    p.priority = priority_dev;
-    p.grad = grad_dev;
-    p.loss_out = loss_dev;
-    const size_t shmem = (size_t)p.tl.total * sizeof(float);
-    if (shmem > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_train_sample),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    hipLaunchKernelGGL(k_train_sample, dim3(batch), dim3(kWave), shmem, st, p);
-    HIP_TRY(hipGetLastError());
-    const int n_grad_blocks = (p.n_params + 255) / 256;
-    const int n_chunks = (batch + kWgradChunk - 1) / kWgradChunk;
-    hipLaunchKernelGGL(k_train_wgrad_partial, dim3(n_grad_blocks, n_chunks), dim3(256), 0, st, p,
-                       h->wgrad_partial_dev);
-    HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_train_wgrad, dim3(n_grad_blocks + 1), dim3(256), 0, st, p,
-                       (const double*)h->wgrad_partial_dev, n_chunks, n_grad_blocks);
-    HIP_TRY(hipGetLastError());
-    return MZS_OK;
+    return train_grad_launch(h, h->tape_layout, h->train_K, batch, obs_dev, actions_dev, target_value_dev,
+                             target_reward_dev, target_policy_dev, is_ratio_dev, inv_global_batch, grad_dev, loss_dev,
+                             priority_dev, h->tape_dev, h->loss_buf_dev, h->wgrad_partial_dev,
+                             static_cast<hipStream_t>(stream));
+}
+
+/* mzs_train_grad without any allocation, neither here nor beforehand (no mzs_train_create): the
+ * per-sample tapes, the per-sample loss terms and the chunk partial sums of the weight gradient
+ * live in this GPU's copy of the static `scratch` array.  Nothing in it has to start at zero:
+ * every element the kernels read is written earlier in the same call (k_train_sample writes the
+ * whole tape row and loss row of each of the `batch` samples, k_train_wgrad_partial every partial
+ * sum k_train_wgrad adds), so stale contents of a previous, larger call are never read. */
+int mzs_train_grad_static(mzs_handle* h, int32_t batch, int32_t unroll_steps, const float* obs_dev,
+                          const float* actions_dev, const float* target_value_dev,
+                          const float* target_reward_dev, const float* target_policy_dev,
+                          const float* is_ratio_dev, float inv_global_batch, float* grad_dev, float* loss_dev,
+                          float* priority_dev, void* stream) {
+    if (!h) return fail(MZS_E_ARG, "null handle");
+    if (!h->have_weights) return fail(MZS_E_STATE, "mzs_set_weights has not been called");
+    if (batch < 1 || unroll_steps < 1) return fail(MZS_E_ARG, "bad batch or unroll length");
+    if (!obs_dev || !actions_dev || !target_value_dev || !target_reward_dev || !target_policy_dev ||
+        !grad_dev || !loss_dev || !priority_dev)
+        return fail(MZS_E_ARG, "null buffer");
+    const mzs_dims& d = h->cfg.dims;
+    if (d.model_kind != MZS_MODEL_MLP) return fail(MZS_E_ARG, "training kernels exist for mlp_model only");
+    if (d.state_dim > 64 || d.n_actions > 64)
+        return fail(MZS_E_ARG, "training kernels hold one logit per lane: state_dim and n_actions <= 64");
+    const TapeLayout tl = make_tape_layout(h->model, unroll_steps);
+    if ((size_t)tl.total * sizeof(float) > (size_t)kMaxLdsPerBlock)
+        return fail(MZS_E_ARG, "one sample's unroll does not fit 160 KiB of LDS");
+    const size_t n = mzs_blob_layout(&d).total;
+    const size_t n_chunks = ((size_t)batch + kWgradChunk - 1) / kWgradChunk;
+    const auto up256 = [](size_t b) { return (b + 255) / 256 * 256; };
+    const size_t tape_bytes = up256((size_t)batch * tl.copy_n * sizeof(float));
+    const size_t loss_bytes = up256((size_t)batch * (3 * (size_t)unroll_steps - 1) * sizeof(float));
+    const size_t part_bytes = up256(n_chunks * n * sizeof(double));
+    if (tape_bytes + loss_bytes + part_bytes > kStaticScratchBytes) {
+        char msg[192];
+        std::snprintf(msg, sizeof msg,
+                      "batch %d x unroll %d needs %zu bytes of scratch, the static array holds %zu "
+                      "(MZS_STATIC_SCRATCH_BYTES): use mzs_train_create + mzs_train_grad for this size",
+                      batch, unroll_steps, tape_bytes + loss_bytes + part_bytes, kStaticScratchBytes);
+        return fail(MZS_E_ARG, msg);
+    }
+    HIP_TRY(hipSetDevice(h->cfg.device));
+    void* sp = nullptr; /* resolved by mzs_create on this device; a table lookup here */
+    const int rc = scratch_for_device(h->cfg.device, &sp);
+    if (rc) return rc;
+    unsigned char* base = static_cast<unsigned char*>(sp);
+    float* tape = reinterpret_cast<float*>(base);
+    float* loss_buf = reinterpret_cast<float*>(base + tape_bytes);
+    double* partial = reinterpret_cast<double*>(base + tape_bytes + loss_bytes);
+    return train_grad_launch(h, tl, unroll_steps, batch, obs_dev, actions_dev, target_value_dev, target_reward_dev,
+                             target_policy_dev, is_ratio_dev, inv_global_batch, grad_dev, loss_dev, priority_dev,
+                             tape, loss_buf, partial, static_cast<hipStream_t>(stream));
 }
 
 int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, double lr, void* stream) {

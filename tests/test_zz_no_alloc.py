@@ -1,0 +1,106 @@
+"""mzs_train_grad_static — the entry point that allocates nothing (include/mzsearch.h): through the
+C-ABI, against mzs_train_grad (the existing entry point whose kernels it shares) on the same
+inputs, bit for bit, on two calls in a row, the second with a smaller batch (the static scratch
+array keeps the first call's contents)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from test_train_oracle import step_inputs
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _grad_existing(fx, inp, B, K):
+    """mzs_train_create + mzs_train_grad on a handle of its own."""
+    import torch
+    from muzero_amd.engine import SearchEngine
+    from muzero_amd.train import Trainer
+    eng = SearchEngine(tuple(int(x) for x in fx["dims"]), max_games=1, max_simulations=0)
+    eng.set_weights(fx["blob0"])
+    tr = Trainer(eng, K, B, "adam", 0.01)
+    prio = tr.grad_step(inp["obs"], inp["actions"], inp["target_value"], inp["target_reward"],
+                        inp["target_policy"], inp["is_ratio"])
+    torch.cuda.synchronize()
+    out = dict(grad=tr.grad.cpu().numpy().copy(), loss=tr.loss.cpu().numpy().copy(), prio=prio.cpu().numpy().copy())
+    eng.close()
+    return out
+
+
+def _grad_static(eng, inp, B, K):
+    """mzs_train_grad_static on a handle that never saw mzs_train_create."""
+    import torch
+    from muzero_amd import _lib
+    dev = eng.device
+    t = {k: (None if v is None else torch.as_tensor(np.ascontiguousarray(v, np.float32)).to(dev))
+         for k, v in inp.items()}
+    grad = torch.full((eng.weight_count(),), np.nan, dtype=torch.float32, device=dev)
+    loss = torch.full((3 * K,), np.nan, dtype=torch.float32, device=dev)
+    prio = torch.full((K, B), np.nan, dtype=torch.float32, device=dev)
+    _lib.check(eng.lib.mzs_train_grad_static(eng.h, B, K, _p(t["obs"]), _p(t["actions"]), _p(t["target_value"]),
+                                             _p(t["target_reward"]), _p(t["target_policy"]), _p(t["is_ratio"]),
+                                             C.c_float(1.0 / B), _p(grad), _p(loss), _p(prio), eng._stream()),
+               "mzs_train_grad_static")
+    torch.cuda.synchronize()
+    return dict(grad=grad.cpu().numpy(), loss=loss.cpu().numpy(), prio=prio.cpu().numpy())
+
+
+def _slice(inp, n):
+    return dict(obs=inp["obs"][:n], actions=inp["actions"][:, :n], target_value=inp["target_value"][:, :n],
+                target_reward=inp["target_reward"][:, :n], target_policy=inp["target_policy"][:, :n],
+                is_ratio=None if inp["is_ratio"] is None else inp["is_ratio"][:n])
+
+
+def _same_bits(a, b):
+    return np.array_equal(np.ascontiguousarray(a).view(np.uint32), np.ascontiguousarray(b).view(np.uint32))
+
+
+def test_static_scratch_entry_point_equals_train_grad():
+    from muzero_amd import _lib
+    from muzero_amd.engine import SearchEngine
+    fx = load_golden("train_tag123_K5_B128.npz")
+    K, B = int(fx["K"]), int(fx["B"])
+    full = step_inputs(fx, 0)
+    eng = SearchEngine(tuple(int(x) for x in fx["dims"]), max_games=1, max_simulations=0)
+    eng.set_weights(fx["blob0"])
+    # two calls in a row on the same GPU's scratch: B = 128, then B = 40 (stale rows 40..127 behind it)
+    for n in (B, 40, B):
+        inp = _slice(full, n)
+        want = _grad_existing(fx, inp, n, K)
+        got = _grad_static(eng, inp, n, K)
+        assert np.isfinite(got["grad"]).all() and np.isfinite(got["loss"]).all() and np.isfinite(got["prio"]).all()
+        for k in ("grad", "loss", "prio"):
+            assert _same_bits(got[k], want[k]), f"batch {n}: {k} differs from mzs_train_grad"
+    # a size beyond the static array is refused with a clear error, before any launch
+    big = 200000
+    import torch
+    z = torch.zeros(8, device=eng.device)
+    rc = eng.lib.mzs_train_grad_static(eng.h, big, K, _p(z), _p(z), _p(z), _p(z), _p(z), None, C.c_float(1.0),
+                                       _p(z), _p(z), _p(z), eng._stream())
+    assert rc == -1 and b"MZS_STATIC_SCRATCH_BYTES" in eng.lib.mzs_last_error()
+    with pytest.raises(_lib.MzsError, match="unroll"):
+        _lib.check(eng.lib.mzs_train_grad_static(eng.h, 4, 0, _p(z), _p(z), _p(z), _p(z), _p(z), None,
+                                                 C.c_float(1.0), _p(z), _p(z), _p(z), eng._stream()), "static")
+    eng.close()
+
+
+def test_static_scratch_other_shape_and_unroll():
+    """A second model shape / unroll length through the same scratch array (L = 4 tied mid layers,
+    K = 3, B = 32, no importance-sampling ratio where the fixture has none)."""
+    from muzero_amd.engine import SearchEngine
+    fx = load_golden("train_tag133_K3_B32.npz")
+    K, B = int(fx["K"]), int(fx["B"])
+    inp = step_inputs(fx, 0)
+    eng = SearchEngine(tuple(int(x) for x in fx["dims"]), max_games=1, max_simulations=0)
+    eng.set_weights(fx["blob0"])
+    want = _grad_existing(fx, inp, B, K)
+    got = _grad_static(eng, inp, B, K)
+    for k in ("grad", "loss", "prio"):
+        assert _same_bits(got[k], want[k]), k
+    eng.close()
