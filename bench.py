@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 F32_MATRIX_PEAK_TFLOPS = 157.3  # fp32 MFMA == fp32 vector peak
+BF16_MATRIX_PEAK_TFLOPS = 16 * 157.3   # dense bf16 MFMA (guide: ~2.5 PF = 16x the fp32 matrix rate)
 
 
 def algorithmic_bytes_per_sim(A, S_dim, dbar):
@@ -90,6 +91,9 @@ def main():
     ap.add_argument("--games", type=int, default=4096, help="games per GPU")
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--weights", default="tag123")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
+                    help="f32: the bit-exact headline; bf16: the 1e-2 variant (weights / layer inputs in bfloat16, "
+                         "v_mfma_f32_4x4x4_16B_bf16), its own roofline against the bf16 matrix peak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--copy-back", action="store_true", help="read results back with a copy launch per step")
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
@@ -118,7 +122,7 @@ def main():
 
     w = np.load(os.path.join(ROOT, "tests", "golden", f"weights_{args.weights}.npz"))
     kind = int(w["kind"]) if "kind" in w.files else 0
-    dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (kind,)
+    dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (kind, 1 if args.dtype == "bf16" else 0)
     obs_dim, A, S_dim, H, L = dims[:5]
     model_name = "LSTM" if kind == 1 else "MLP"
     G, S = args.games, args.sims
@@ -197,7 +201,7 @@ def main():
         "metric": "MCTS sims/sec (whole node), CartPole MLP, 50 sims x 4096 games/GPU",
         "value": value, "unit": "sims/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype,
         "data": f"synthetic (obs ~ U(-0.05,0.05)^{obs_dim}, {args.weights} fixture weights, per-game "
                 "RandomState streams pre-drawn on host and resident in HBM)",
         "config": {"workload": f"{'C2: CartPole-v1 ' if args.weights == 'tag123' else ''}{model_name} obs{obs_dim} A{A} "
@@ -229,8 +233,11 @@ def main():
                 traffic = tj["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
-        out["roofline"] = {"bound": "mfma", "achieved": fl, "peak": F32_MATRIX_PEAK_TFLOPS,
-                           "unit": "TFLOP/s", "frac": fl / F32_MATRIX_PEAK_TFLOPS, "traffic": traffic,
+        peak = BF16_MATRIX_PEAK_TFLOPS if args.dtype == "bf16" else F32_MATRIX_PEAK_TFLOPS
+        if args.dtype == "bf16":
+            traffic = None      # profiles/traffic.json is the fp32 kernel's
+        out["roofline"] = {"bound": "mfma", "achieved": fl, "peak": peak,
+                           "unit": "TFLOP/s", "frac": fl / peak, "traffic": traffic,
                            "kernel": kernel_name, "kernel_ms": kernel_ms,
                            "flops_per_sim": fps, "mean_path_len": dbar,
                            "hbm_equiv": {"achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -238,8 +245,8 @@ def main():
                            "note": "neither roofline binds at this model size: one wave per SIMD, "
                                    "instruction issue 63 % / LDS and memory waits 31 % of wave cycles "
                                    "(profiles/r1h_quad_summary.md, DESIGN.md 4)"}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(dims, w["blob"], S, eng.pbc)
+        if world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
+            out["cpu_baseline"] = cpu_baseline(dims[:6], w["blob"], S, eng.pbc)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

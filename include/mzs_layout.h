@@ -37,7 +37,13 @@ typedef struct mzs_dims {
     int32_t n_mid_layers; /* L: how many times the tied mid layer is applied (MLP);
                              num_layers of every nn.LSTM (LSTM model, 1..MZS_LSTM_MAX_LAYERS) */
     int32_t model_kind;   /* MZS_MODEL_MLP (0, 'mlp_model') or MZS_MODEL_LSTM ('lstm_model')    */
+    int32_t precision;    /* MZS_PRECISION_F32 (0) or MZS_PRECISION_BF16: Muzero(type_format=...),
+                             muzero_model.py:194-204.  bf16 = weights and layer inputs rounded to
+                             bfloat16, fp32 accumulation and epilogues (include/mzs_numeric.h)   */
 } mzs_dims;
+
+#define MZS_PRECISION_F32 0
+#define MZS_PRECISION_BF16 1
 
 #define MZS_MODEL_MLP 0
 #define MZS_MODEL_LSTM 1

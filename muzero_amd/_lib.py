@@ -25,7 +25,8 @@ class MzsError(RuntimeError):
 
 class Dims(C.Structure):
     _fields_ = [("obs_dim", C.c_int32), ("n_actions", C.c_int32), ("state_dim", C.c_int32),
-                ("hidden_dim", C.c_int32), ("n_mid_layers", C.c_int32), ("model_kind", C.c_int32)]
+                ("hidden_dim", C.c_int32), ("n_mid_layers", C.c_int32), ("model_kind", C.c_int32),
+                ("precision", C.c_int32)]
 
 
 class ArenaConfig(C.Structure):
@@ -37,6 +38,7 @@ ARENA_LENGTH, ARENA_OBS, ARENA_ACTION, ARENA_REWARD, ARENA_ROOT_VALUE, ARENA_POL
 ARENA_ALIVE, ARENA_STATE, ARENA_STREAM_SEED, ARENA_SLOT_ROW = 6, 7, 8, 9
 ENV_CARTPOLE = 0
 MODEL_MLP, MODEL_LSTM = 0, 1
+PRECISION_F32, PRECISION_BF16 = 0, 1
 
 
 class Config(C.Structure):

@@ -51,6 +51,7 @@ struct LstmHead {
 struct Model {
     int obs_dim, A, Sd, H, L;
     int kind;       /* MZS_MODEL_MLP / MZS_MODEL_LSTM (include/mzs_layout.h)                 */
+    int bf16;       /* 1: contract "dot_bf16" (include/mzs_numeric.h); w then holds bf16-rounded weights */
     int seg_state;  /* offset of the next-state segment in the dynamics heads (reward at 0) */
     int seg_value;  /* offset of the value segment in the prediction heads (policy at 0)     */
     Layer r_in, r_mid, r_out, d_in, d_mid, d_heads, p_in, p_mid, p_heads;
@@ -172,8 +173,46 @@ __device__ __forceinline__ float wave_tree_sum(float v) {
  * extra_row >= 0 adds that row of W^T after the chain (the one-hot action column of
  * the dynamics input, neural_network_mlp_model.py:87 + muzero_model.py:502). */
 template <bool kElu>
+__device__ __forceinline__ void wave_dense_bf16(const float* __restrict__ w, const Layer ly, const float* x,
+                                                float* out, int extra_row, int lane) {
+    /* contract "dot_bf16" without the matrix core (the any-shape kernels): mzs_dot4_bf16 restates
+     * what one v_mfma_f32_4x4x4_16B_bf16 returns, so this and the MFMA kernels agree bit for bit.
+     * The store holds the weights already rounded to bfloat16 (as floats): their high halves. */
+    const int ng = (ly.k + 3) / 4;
+    for (int j0 = 0; j0 < ly.n_pad; j0 += kWave) {
+        const int j = j0 + lane;
+        const float* __restrict__ wt = w + ly.w_off + j;
+        float e = w[ly.b_off + j], o = 0.0f;
+        for (int g = 0; g < ng; ++g) {
+            unsigned short wb[4], xb[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * g + q;
+                const bool in = k < ly.k;
+                wb[q] = in ? (unsigned short)((unsigned)mzs_f2bits(wt[(size_t)k * ly.n_pad]) >> 16) : (unsigned short)0;
+                xb[q] = in ? mzs_f2bf16(x[k]) : (unsigned short)0;
+            }
+            const float d = mzs_dot4_bf16(wb, xb);
+            if (g & 1)
+                o = g == 1 ? d : o + d;
+            else
+                e = e + d;
+        }
+        float acc = e + o;
+        if (extra_row >= 0) acc = acc + wt[(size_t)extra_row * ly.n_pad];
+        if (kElu) acc = mzs_elu(acc);
+        out[j] = acc;
+    }
+    wave_sync();
+}
+
+template <bool kElu>
 __device__ __forceinline__ void wave_dense(const float* __restrict__ w, const Layer ly,
-                                           const float* x, float* out, int extra_row, int lane) {
+                                           const float* x, float* out, int extra_row, int lane, int bf16 = 0) {
+    if (bf16) {
+        wave_dense_bf16<kElu>(w, ly, x, out, extra_row, lane);
+        return;
+    }
     for (int j0 = 0; j0 < ly.n_pad; j0 += kWave) {
         const int j = j0 + lane;
         const float* __restrict__ wt = w + ly.w_off + j;
@@ -209,7 +248,7 @@ __device__ __forceinline__ void wave_dense(const float* __restrict__ w, const La
 __device__ __forceinline__ float* wave_mid_layers(const Model& m, const Layer ly, float* in,
                                                   float* other, int lane) {
     for (int l = 0; l < m.L; ++l) {
-        wave_dense<true>(m.w, ly, in, other, -1, lane);
+        wave_dense<true>(m.w, ly, in, other, -1, lane, m.bf16);
         float* t = in;
         in = other;
         other = t;
@@ -285,10 +324,10 @@ __device__ __forceinline__ void seg_scale_to_bound(const float* seg, int n, floa
  * three columns of one fused dense layer, then the cell step is lane-local. */
 __device__ __forceinline__ float* lstm_head(const Model& m, const LstmHead& hd, const WaveLds& L,
                                             const float* x, int extra_row, int lane) {
-    wave_dense<false>(m.w, hd.lin, x, L.xa, extra_row, lane);
+    wave_dense<false>(m.w, hd.lin, x, L.xa, extra_row, lane, m.bf16);
     float *cur = L.xa, *nxt = L.xb;
     for (int l = 0; l < m.L; ++l) {
-        wave_dense<false>(m.w, hd.gate[l], cur, L.ob, -1, lane);
+        wave_dense<false>(m.w, hd.gate[l], cur, L.ob, -1, lane, m.bf16);
         const float* bh = m.w + hd.bhh_off[l];
         for (int j = lane; j < hd.n_out; j += kWave) {
             const float gi = L.ob[j] + bh[j];
@@ -318,13 +357,13 @@ __device__ __forceinline__ void seg_copy(const float* src, int n, float* dst, fl
 __device__ __forceinline__ void model_representation(const Model& m, const WaveLds& L,
                                                      float* gdst, int lane) {
     if (m.kind == MZS_MODEL_LSTM) { /* one Linear (neural_network_lstm_model.py:19-21) */
-        wave_dense<false>(m.w, m.r_in, L.xh, L.ob, -1, lane);
+        wave_dense<false>(m.w, m.r_in, L.xh, L.ob, -1, lane, m.bf16);
         seg_copy(L.ob, m.Sd, L.xh, gdst, lane);
         return;
     }
-    wave_dense<true>(m.w, m.r_in, L.xh, L.xa, -1, lane);
+    wave_dense<true>(m.w, m.r_in, L.xh, L.xa, -1, lane, m.bf16);
     float* t = wave_mid_layers(m, m.r_mid, L.xa, L.xb, lane);
-    wave_dense<false>(m.w, m.r_out, t, L.ob, -1, lane);
+    wave_dense<false>(m.w, m.r_out, t, L.ob, -1, lane, m.bf16);
     seg_scale_to_bound(L.ob, m.Sd, L.xh, gdst, lane);
 }
 
@@ -340,9 +379,9 @@ __device__ __forceinline__ float model_dynamics(const Model& m, const WaveLds& L
         seg_copy(s, m.Sd, L.xh, gdst, lane);
         return reward;
     }
-    wave_dense<true>(m.w, m.d_in, L.xh, L.xa, m.Sd + action, lane);
+    wave_dense<true>(m.w, m.d_in, L.xh, L.xa, m.Sd + action, lane, m.bf16);
     float* t = wave_mid_layers(m, m.d_mid, L.xa, L.xb, lane);
-    wave_dense<false>(m.w, m.d_heads, t, L.ob, -1, lane);
+    wave_dense<false>(m.w, m.d_heads, t, L.ob, -1, lane, m.bf16);
     const float reward = seg_support_scalar(L.ob, m.Sd, lane);
     seg_scale_to_bound(L.ob + m.seg_state, m.Sd, L.xh, gdst, lane);
     return reward;
@@ -358,9 +397,9 @@ __device__ __forceinline__ float model_prediction(const Model& m, const WaveLds&
         const float* vl = lstm_head(m, m.l_val, L, L.xh, -1, lane);
         return seg_support_scalar(vl, m.Sd, lane);
     }
-    wave_dense<true>(m.w, m.p_in, L.xh, L.xa, -1, lane);
+    wave_dense<true>(m.w, m.p_in, L.xh, L.xa, -1, lane, m.bf16);
     float* t = wave_mid_layers(m, m.p_mid, L.xa, L.xb, lane);
-    wave_dense<false>(m.w, m.p_heads, t, L.ob, -1, lane);
+    wave_dense<false>(m.w, m.p_heads, t, L.ob, -1, lane, m.bf16);
     *policy = seg_softmax(seg_load(L.ob, m.A, lane));
     return seg_support_scalar(L.ob + m.seg_value, m.Sd, lane);
 }

@@ -409,7 +409,8 @@ __global__ void __launch_bounds__(256) k_train_wgrad(const TrainParams p, const 
 struct ApplyParams {
     float* blob;
     float* store;
-    const int* store_index; /* blob element -> offset in the device weight store */
+    float* store16;         /* MZS_PRECISION_BF16: the search's copy (weights rounded to bfloat16), else null */
+    const int* store_index; /* blob element -> offset in the device weight store; bit 30: a bias */
     float* m;
     float* v;
     const float* grad;
@@ -438,7 +439,9 @@ __global__ void __launch_bounds__(256) k_train_apply(const ApplyParams p) {
         w = w - p.lr * buf;
     }
     p.blob[i] = w;
-    p.store[p.store_index[i]] = w;
+    const int si = p.store_index[i], so = si & 0x3fffffff;
+    p.store[so] = w;
+    if (p.store16) p.store16[so] = (si >> 30) ? w : mzs_bf16_round(w);
 }
 
 }  // namespace mzs

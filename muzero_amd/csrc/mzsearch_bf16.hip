@@ -1,0 +1,30 @@
+/*
+ * mzsearch_bf16.hip — the bf16 instantiations of k_search_quad (mzs_search_kernels.h,
+ * mzs_quad_bf16.h), a translation unit of their own because they want MFMA results in VGPRs
+ * (-mllvm -amdgpu-mfma-vgpr-form, see muzero_amd/csrc/Makefile); part of libmzsearch.so.
+ */
+#include <hip/hip_runtime.h>
+
+#include "mzs_search_kernels.h"
+
+namespace mzs {
+
+/* bf16 (contract "dot_bf16"): the benchmark shape and its A = 4 sibling, with or without tied mid layers */
+template <bool kHidG>
+static quad_kernel_t pick_quad_kernel_b16_t(const mzs_dims& d) {
+    if (d.obs_dim > 64 || d.model_kind != MZS_MODEL_MLP) return nullptr;
+    const bool mid = d.n_mid_layers != 0;
+    if (d.state_dim == 31 && d.hidden_dim == 64) {
+        switch (d.n_actions) {
+            case 2: return mid ? k_search_quad<31, 2, 64, false, true, kHidG, true> : k_search_quad<31, 2, 64, false, false, kHidG, true>;
+            case 4: return mid ? k_search_quad<31, 4, 64, false, true, kHidG, true> : k_search_quad<31, 4, 64, false, false, kHidG, true>;
+            default: return nullptr;
+        }
+    }
+    return nullptr;
+}
+quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global) {
+    return hid_global ? pick_quad_kernel_b16_t<true>(d) : pick_quad_kernel_b16_t<false>(d);
+}
+
+}  // namespace mzs

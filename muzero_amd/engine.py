@@ -28,9 +28,9 @@ def _ptr(t):
 class SearchEngine:
     """Batched Monte_carlo_tree_search over `max_games` concurrent games.
 
-    dims = (obs_dim, n_actions, state_dim, hidden_dim, n_mid_layers[, model_kind]) — the shapes the
-    reference passes to Muzero(...) (muzero_model.py:16-35; model_kind 0 = 'mlp_model', 1 =
-    'lstm_model'); discount / pb_c_* /
+    dims = (obs_dim, n_actions, state_dim, hidden_dim, n_mid_layers[, model_kind[, precision]]) — the
+    shapes the reference passes to Muzero(...) (muzero_model.py:16-35; model_kind 0 = 'mlp_model', 1 =
+    'lstm_model'; precision 0 = fp32, 1 = bf16 as type_format=torch.bfloat16); discount / pb_c_* /
     root_exploration_fraction are the Monte_carlo_tree_search ctor arguments
     (monte_carlo_tree_search.py:38).
     """
@@ -44,6 +44,7 @@ class SearchEngine:
         self.dims = tuple(int(x) for x in dims)
         self.obs_dim, self.A, self.S_dim, self.H, self.L = self.dims[:5]
         self.model_kind = self.dims[5] if len(self.dims) > 5 else _lib.MODEL_MLP
+        self.precision = self.dims[6] if len(self.dims) > 6 else _lib.PRECISION_F32
         self.max_games, self.max_simulations = int(max_games), int(max_simulations)
         self.discount = float(discount)
         self.frac = float(root_exploration_fraction)

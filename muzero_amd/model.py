@@ -80,8 +80,9 @@ def lstm_blob_layout(obs_dim, A, S_dim, H, L):
             head("d_st", S_dim + A, S_dim) + head("p_pol", S_dim, A) + head("p_val", S_dim, S_dim))
 
 
-def blob_layout(obs_dim, A, S_dim, H, L, kind=0):
-    """(name, shape) of every tensor in the packed blob, in order (include/mzs_layout.h)."""
+def blob_layout(obs_dim, A, S_dim, H, L, kind=0, precision=0):
+    """(name, shape) of every tensor in the packed blob, in order (include/mzs_layout.h).  The blob
+    is fp32 whatever the compute precision (bf16 rounds a copy of it on the device)."""
     if kind == _lib.MODEL_LSTM:
         return lstm_blob_layout(obs_dim, A, S_dim, H, L)
     mid = lambda p: [(f"{p}_mid_w", (H, H)), (f"{p}_mid_b", (H,))] if L > 0 else []  # noqa: E731
@@ -139,8 +140,11 @@ class Muzero:
                                       "have MI355X kernels (SURVEY.md §8f lists the others as next)")
         if model_structure == "lstm_model" and not 1 <= int(number_of_hidden_layer) <= 4:
             raise ValueError("lstm_model: number_of_hidden_layer is nn.LSTM's num_layers, 1..4 here")
-        if type_format not in (torch.float32, None) or use_amp:
-            raise NotImplementedError("the search path computes in fp32 (bit-exact contract)")
+        if type_format not in (torch.float32, torch.bfloat16, None):
+            raise NotImplementedError(f"type_format={type_format}: torch.float32 (bit-exact contract) or "
+                                      "torch.bfloat16 (1e-2 contract, include/mzs_numeric.h)")
+        if use_amp and type_format is not torch.bfloat16:
+            raise NotImplementedError("use_amp: mixed precision exists as type_format=torch.bfloat16 only")
         self.model_structure = model_structure or "mlp_model"
         self.state_dimension = state_space_dimensions
         self.hidden_layer_dimension = hidden_layer_dimensions
@@ -149,8 +153,14 @@ class Muzero:
         self.loss_type, self.lr, self.opt, self.sch = loss_type, learning_rate, optimizer, lr_scheduler
         self.epoch, self.count = num_of_epoch, 0
         self.device = "cuda" if device in ("cpu", None) else device  # there is no CPU path
-        self.type_format = torch.float32
-        self.use_amp, self.scaler_on = False, False
+        # bf16: weights and layer inputs rounded to bfloat16 on the device, fp32 accumulation and
+        # epilogues, fp32 master weights and fp32 training.  The reference sets use_amp for every
+        # "float16" type (muzero_model.py:202: bfloat16 matches the substring) and keeps fp32 weights
+        # under torch.autocast; its own bf16 VALUE output collapses to -1 (inverse_transform_with_support
+        # runs in bfloat16 outside autocast, muzero_model.py:903) — not reproduced, see DESIGN.md.
+        self.type_format = torch.bfloat16 if type_format is torch.bfloat16 else torch.float32
+        self.precision = _lib.PRECISION_BF16 if self.type_format is torch.bfloat16 else _lib.PRECISION_F32
+        self.use_amp, self.scaler_on = self.precision == _lib.PRECISION_BF16, False
         self.random_tag = np.random.randint(0, 100000000)  # muzero_model.py:213 (global stream)
         self.store_loss = []
         self.bin_method, self.bin_decomposition_number = bin_method, bin_decomposition_number
@@ -170,10 +180,11 @@ class Muzero:
     # ------------------------------------------------------------------ weights
     @property
     def dims(self):
-        return (int(self.observation_dimension), int(self.action_dimension),
-                int(self.state_dimension), int(self.hidden_layer_dimension),
-                int(self.number_of_hidden_layer),
-                _lib.MODEL_LSTM if self.model_structure == "lstm_model" else _lib.MODEL_MLP)
+        d = (int(self.observation_dimension), int(self.action_dimension),
+             int(self.state_dimension), int(self.hidden_layer_dimension),
+             int(self.number_of_hidden_layer),
+             _lib.MODEL_LSTM if self.model_structure == "lstm_model" else _lib.MODEL_MLP)
+        return d + (self.precision,) if self.precision else d
 
     def initiate_model_weight(self):
         """weights_init (neural_network_mlp_model.py:287-292): N(0, 1/137.035999) for every
@@ -321,7 +332,7 @@ class Muzero:
                 "optimizer": self.opt, "loss_type": self.loss_type, "lr_scheduler": self.sch,
                 "num_of_epoch": self.epoch, "device": self.device, "random_tag": self.random_tag,
                 "action_map": self.action_dictionnary, "model_structure": self.model_structure,
-                "use_amp": self.use_amp}
+                "use_amp": self.use_amp, "type_format": str(self.type_format)}
 
     def save_model(self, directory="model_checkpoint", tag=None, model_update_condition=None):
         """Same JSON as muzero_model.py:923-941; the weights go to one `.npz` blob instead of
@@ -349,7 +360,8 @@ class Muzero:
                    loss_type=iv["loss_type"], device=device or iv["device"],
                    num_of_epoch=iv["num_of_epoch"],
                    hidden_layer_dimensions=iv["hidden_layer_dimensions"],
-                   number_of_hidden_layer=iv["number_of_hidden_layer"], load=True)
+                   number_of_hidden_layer=iv["number_of_hidden_layer"], load=True,
+                   type_format=torch.bfloat16 if "bfloat16" in str(iv.get("type_format", "")) else torch.float32)
         self.observation_dimension = iv["observation_space_dimensions"]
         self.action_dictionnary = iv["action_map"]
         self.action_dimension = len(self.action_dictionnary)

@@ -12,10 +12,30 @@
 
 /* ------------------------------------------------------------------ model */
 
+/* contract "dot_bf16" (include/mzs_numeric.h): weights and inputs rounded to bfloat16, groups of
+ * four consecutive k through mzs_dot4_bf16, even groups chained from the bias, odd groups from the
+ * first odd group, one add */
+static void dense_bf16(const float* W, const float* b, const float* x, int nout, int nin, int ldw, float* y) {
+    const int ng = (nin + 3) / 4;
+    unsigned short* xb = (unsigned short*)malloc(sizeof(unsigned short) * (size_t)ng * 4 * 2);
+    unsigned short* wb = xb + (size_t)ng * 4;
+    for (int k = 0; k < ng * 4; ++k) xb[k] = k < nin ? mzs_f2bf16(x[k]) : 0;
+    for (int j = 0; j < nout; ++j) {
+        const float* w = W + (size_t)j * ldw;
+        for (int k = 0; k < ng * 4; ++k) wb[k] = k < nin ? mzs_f2bf16(w[k]) : 0;
+        float e = b[j], o = 0.0f;
+        for (int g = 0; g < ng; g += 2) e = e + mzs_dot4_bf16(wb + 4 * g, xb + 4 * g);
+        if (ng > 1) o = mzs_dot4_bf16(wb + 4, xb + 4);
+        for (int g = 3; g < ng; g += 2) o = o + mzs_dot4_bf16(wb + 4 * g, xb + 4 * g);
+        y[j] = e + o;
+    }
+    free(xb);
+}
+
 /* contract "dot": even-k chain from the bias, odd-k chain from zero, one add.
  * W row-major [nout][ldw]. */
-static void dense(const float* W, const float* b, const float* x, int nout, int nin, int ldw,
-                  float* y) {
+static void dense_f32(const float* W, const float* b, const float* x, int nout, int nin, int ldw,
+                      float* y) {
     for (int j = 0; j < nout; ++j) {
         float e = b[j], o = 0.0f;
         const float* w = W + (size_t)j * ldw;
@@ -24,6 +44,18 @@ static void dense(const float* W, const float* b, const float* x, int nout, int 
         y[j] = e + o;
     }
 }
+
+/* the model's precision picks the contract; every layer of every net goes through here */
+static int g_bf16 = 0;
+#pragma omp threadprivate(g_bf16)
+static void dense(const float* W, const float* b, const float* x, int nout, int nin, int ldw, float* y) {
+    if (g_bf16)
+        dense_bf16(W, b, x, nout, nin, ldw, y);
+    else
+        dense_f32(W, b, x, nout, nin, ldw, y);
+}
+/* a weight used outside a dot (the one-hot action column): rounded like every other weight */
+static float weight_value(float w) { return g_bf16 ? mzs_bf16_round(w) : w; }
 
 static void elu_inplace(float* x, int n) {
     for (int i = 0; i < n; ++i) x[i] = mzs_elu(x[i]);
@@ -74,6 +106,13 @@ void mzo_scale_to_bound(const float* x, int32_t n, float* y) {
 }
 
 float mzo_expf(float x) { return mzs_expf(x); }
+/* contract "dot_bf16" pieces, exported so that tests can pin them to recorded device outputs */
+void mzo_dot4_bf16(const uint16_t* a, const uint16_t* b, int32_t n, float* out) {
+    for (int i = 0; i < n; ++i) out[i] = mzs_dot4_bf16(a + 4 * (size_t)i, b + 4 * (size_t)i);
+}
+void mzo_round_bf16(const float* x, int32_t n, float* out) {
+    for (int i = 0; i < n; ++i) out[i] = mzs_bf16_round(x[i]);
+}
 float mzo_elu(float x) { return mzs_elu(x); }
 
 /* tied mid layer applied L times (neural_network_mlp_model.py:38-39) */
@@ -110,7 +149,7 @@ static void lstm_head(const mzs_dims* d, const float* blob, const mzs_lstm_head_
     const int H = d->hidden_dim, n = h->out_dim;
     dense(blob + h->lin_w, blob + h->lin_b, x, H, x_len, h->in_dim, s->t);
     if (extra_col >= 0) /* one-hot action column, as in dyn_one */
-        for (int j = 0; j < H; ++j) s->t[j] = s->t[j] + blob[h->lin_w + (size_t)j * h->in_dim + extra_col];
+        for (int j = 0; j < H; ++j) s->t[j] = s->t[j] + weight_value(blob[h->lin_w + (size_t)j * h->in_dim + extra_col]);
     const float* cur = s->t;
     int in_l = H;
     for (int l = 0; l < d->n_mid_layers; ++l) {
@@ -161,7 +200,7 @@ static void dyn_one(const mzs_dims* d, const float* blob, const mzs_blob_offsets
     const float* W = blob + o->d_in_w;
     dense(W, blob + o->d_in_b, hidden, H, Sd, ld, s->t);
     /* one-hot column: fma(1, w, acc) == acc + w; the zero columns add nothing */
-    for (int j = 0; j < H; ++j) s->t[j] = s->t[j] + W[(size_t)j * ld + Sd + action];
+    for (int j = 0; j < H; ++j) s->t[j] = s->t[j] + weight_value(W[(size_t)j * ld + Sd + action]);
     elu_inplace(s->t, H);
     mid_layers(d, blob + o->d_mid_w, blob + o->d_mid_b, s->t, s->t2);
     dense(blob + o->d_rew_w, blob + o->d_rew_b, s->t, Sd, H, H, s->q);
@@ -196,6 +235,7 @@ void mzo_representation(const mzs_dims* d, const float* blob, const float* obs, 
                         float* hidden) {
     mzs_blob_offsets o = mzs_blob_layout(d);
     scratch s = scratch_new(d);
+    g_bf16 = d->precision == MZS_PRECISION_BF16;
     for (int i = 0; i < B; ++i)
         repr_one(d, blob, &o, obs + (size_t)i * d->obs_dim, hidden + (size_t)i * d->state_dim, &s);
     free(s.t);
@@ -205,6 +245,7 @@ void mzo_dynamics(const mzs_dims* d, const float* blob, const float* hidden,
                   const int32_t* action, int32_t B, float* reward, float* next_hidden) {
     mzs_blob_offsets o = mzs_blob_layout(d);
     scratch s = scratch_new(d);
+    g_bf16 = d->precision == MZS_PRECISION_BF16;
     for (int i = 0; i < B; ++i)
         dyn_one(d, blob, &o, hidden + (size_t)i * d->state_dim, action[i], reward + i,
                 next_hidden + (size_t)i * d->state_dim, &s);
@@ -215,6 +256,7 @@ void mzo_prediction(const mzs_dims* d, const float* blob, const float* hidden, i
                     float* policy, float* value) {
     mzs_blob_offsets o = mzs_blob_layout(d);
     scratch s = scratch_new(d);
+    g_bf16 = d->precision == MZS_PRECISION_BF16;
     for (int i = 0; i < B; ++i)
         pred_one(d, blob, &o, hidden + (size_t)i * d->state_dim, policy + (size_t)i * d->n_actions,
                  value + i, &s);
@@ -394,6 +436,7 @@ int mzo_search(const mzo_search_cfg* cfg, const float* blob, const mzo_table_mod
         T.root_prior = (double*)malloc(sizeof(double) * (size_t)d->n_actions);
         T.hidden = (float*)malloc(sizeof(float) * (size_t)(S + 1) * d->state_dim);
         scratch sc = scratch_new(d);
+        g_bf16 = d->precision == MZS_PRECISION_BF16; /* threadprivate */
 #pragma omp for schedule(static)
         for (int g = 0; g < G; ++g) {
             int r = search_one(cfg, blob, &bo, tbl, obs, dirichlet,

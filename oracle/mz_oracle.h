@@ -79,6 +79,10 @@ void mzo_prediction(const mzs_dims* d, const float* blob, const float* hidden, i
 void mzo_scale_to_bound(const float* x, int32_t n, float* y);
 float mzo_support_to_scalar(const float* logits, int32_t n);
 float mzo_expf(float x);
+/* n groups of four bf16 pairs -> what one v_mfma_f32_4x4x4_16B_bf16 with a zero accumulator returns
+ * (include/mzs_numeric.h mzs_dot4_bf16); round-to-nearest-even fp32 -> bf16 -> fp32 */
+void mzo_dot4_bf16(const uint16_t* a, const uint16_t* b, int32_t n, float* out);
+void mzo_round_bf16(const float* x, int32_t n, float* out);
 float mzo_elu(float x);
 
 /* returns 0, or -1 on a bad argument */

@@ -15,7 +15,8 @@ _LIB = None
 
 class Dims(C.Structure):
     _fields_ = [("obs_dim", C.c_int32), ("n_actions", C.c_int32), ("state_dim", C.c_int32),
-                ("hidden_dim", C.c_int32), ("n_mid_layers", C.c_int32), ("model_kind", C.c_int32)]
+                ("hidden_dim", C.c_int32), ("n_mid_layers", C.c_int32), ("model_kind", C.c_int32),
+                ("precision", C.c_int32)]
 
 
 class SearchCfg(C.Structure):
@@ -63,13 +64,29 @@ def lib():
     return _LIB
 
 
-def dims(obs_dim, A, S_dim, H, L, kind=0):
-    """kind: 0 = 'mlp_model', 1 = 'lstm_model' (include/mzs_layout.h)."""
-    return Dims(int(obs_dim), int(A), int(S_dim), int(H), int(L), int(kind))
+def dims(obs_dim, A, S_dim, H, L, kind=0, precision=0):
+    """kind: 0 = 'mlp_model', 1 = 'lstm_model'; precision: 0 = fp32, 1 = bf16 (include/mzs_layout.h)."""
+    return Dims(int(obs_dim), int(A), int(S_dim), int(H), int(L), int(kind), int(precision))
 
 
 def _p(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def dot4_bf16(a16, b16):
+    """a16, b16: uint16 [n, 4] bf16 bit patterns -> float32 [n] (mzs_dot4_bf16)."""
+    a = np.ascontiguousarray(a16, np.uint16).reshape(-1, 4)
+    b = np.ascontiguousarray(b16, np.uint16).reshape(-1, 4)
+    out = np.empty(len(a), np.float32)
+    lib().mzo_dot4_bf16(_p(a), _p(b), C.c_int32(len(a)), _p(out))
+    return out
+
+
+def round_bf16(x):
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    lib().mzo_round_bf16(_p(x), C.c_int32(x.size), _p(out))
+    return out
 
 
 def _f32(a):
