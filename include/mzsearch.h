@@ -249,6 +249,19 @@ int32_t mzs_arena_n_actions(const mzs_arena* arena);
 int mzs_arena_begin(mzs_arena* arena, int32_t row0, int32_t n_games, const int64_t* seeds_dev, int32_t episode,
                     float* obs_dev, void* stream);
 
+/* More games behind the end of the queue mzs_arena_begin started (learning_cycle's NEXT iteration
+ * of play_game calls, self_play.py:217-236, queued while the current one still plays): game i is
+ * recorded in trajectory row (v + i) % n_rows, v = the queue's end — rows are a ring, the caller
+ * keeps n_rows large enough that rows still in its replay window are not overwritten.  The games
+ * start in the slots freed by finished ones, in queue order, so the lock-step searches stay full
+ * across iteration boundaries (a round that ends with its queue empty runs its last moves on
+ * ever fewer live slots).  `episode` keys the games' random numbers, `temperature` is their
+ * action-selection temperature (NaN: the temperature argument of each mzs_arena_step).
+ * MZS_ARENA_QUEUE: i32 [3] virtual rows {next unplayed, queue end, done_upto}: every game below
+ * done_upto has finished. */
+int mzs_arena_enqueue(mzs_arena* arena, int32_t n_games, const int64_t* seeds_dev, int32_t episode,
+                      double temperature, void* stream);
+
 /* One move of every live slot, fed with this move's search results (mzs_results layout):
  * Game.store_search_statistics (game.py:154-168), Game.policy_step (game.py:176-225: temperature
  * rescale, np.random.choice above temperature 0.1 else argmax, env.step, append to the lists);
@@ -289,6 +302,7 @@ int mzs_arena_priority(mzs_arena* arena, int32_t row0, int32_t n_rows, int32_t t
 #define MZS_ARENA_STATE 7      /* f64 [n_slots][4]              environment state       */
 #define MZS_ARENA_STREAM_SEED 8 /* i64 [n_slots]                seed of the next search streams */
 #define MZS_ARENA_SLOT_ROW 9   /* i32 [n_slots]                 row the slot records into */
+#define MZS_ARENA_QUEUE 10     /* i32 [3]                       virtual rows: next unplayed, queue end, done_upto */
 void* mzs_arena_array(mzs_arena* arena, int32_t which);
 
 /* ---- replay store, host side (CPU only; no GPU work, callable without a device).

@@ -35,7 +35,7 @@ class ArenaConfig(C.Structure):
 
 
 ARENA_LENGTH, ARENA_OBS, ARENA_ACTION, ARENA_REWARD, ARENA_ROOT_VALUE, ARENA_POLICY = 0, 1, 2, 3, 4, 5
-ARENA_ALIVE, ARENA_STATE, ARENA_STREAM_SEED, ARENA_SLOT_ROW = 6, 7, 8, 9
+ARENA_ALIVE, ARENA_STATE, ARENA_STREAM_SEED, ARENA_SLOT_ROW, ARENA_QUEUE = 6, 7, 8, 9, 10
 ENV_CARTPOLE = 0
 MODEL_MLP, MODEL_LSTM = 0, 1
 PRECISION_F32, PRECISION_BF16 = 0, 1
@@ -89,6 +89,7 @@ _SIGNATURES = {
     "mzs_arena_n_actions": (C.c_int32, [C.c_void_p]),
     "mzs_arena_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_void_p]),
+    "mzs_arena_enqueue": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
     "mzs_arena_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
     "mzs_arena_make_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,

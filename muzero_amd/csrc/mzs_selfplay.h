@@ -29,9 +29,13 @@ struct ArenaArrays {
     long long* seed;        /* [G]    seed of the slot's current game                       */
     int* episode;           /* [G]    round counter (random-number key)                     */
     long long* stream_seed; /* [G]    RandomState seed of the slot's next search streams    */
-    int* ctl;               /* [2]    next unplayed row, end of this round's rows           */
+    int* vrow;              /* [G]    virtual row of the slot's game (row = vrow % n_rows)   */
+    int* ctl;               /* [3]    VIRTUAL rows (they never wrap): next unplayed game, end of the queue,
+                                      and the row every game below which has finished         */
     /* per trajectory row (replaces the Game object's lists, game.py:46-55) */
     long long* row_seed;    /* [n_rows]          seed of the game recorded in the row       */
+    int* row_episode;       /* [n_rows]          random-number key: the round the game was queued for */
+    double* row_temp;       /* [n_rows]          action-selection temperature of the game; NaN: the step's */
     int* length;            /* [n_rows]          game_length                                */
     float* obs;             /* [n_rows][T][obs]  observations (state AFTER move t, as Game stores it) */
     int* action;            /* [n_rows][T]       action_history (index; one-hot when gathered) */
@@ -47,14 +51,17 @@ __device__ __forceinline__ long long arena_stream_seed(long long seed, int episo
 }
 
 /* Game() + Game.observation(iteration=0) (game.py:126-141) for slot g, recording into `row` */
-__device__ __forceinline__ void arena_start_game(const ArenaArrays& a, int g, int row, long long seed,
-                                                 int episode, float* obs_io) {
+__device__ __forceinline__ void arena_start_game(const ArenaArrays& a, int g, int vrow, float* obs_io) {
+    const int row = vrow % a.n_rows;
+    const long long seed = a.row_seed[row];
+    const int episode = a.row_episode[row];
     mzs_cartpole st;
     mzs_cartpole_reset(&st, (uint64_t)seed, (uint32_t)episode);
     double* s = a.state + (size_t)g * 4;
     s[0] = st.x, s[1] = st.x_dot, s[2] = st.theta, s[3] = st.theta_dot;
     a.alive[g] = 1;
     a.row[g] = row;
+    a.vrow[g] = vrow;
     a.seed[g] = seed;
     a.episode[g] = episode;
     a.stream_seed[g] = arena_stream_seed(seed, episode, 0);
@@ -64,25 +71,42 @@ __device__ __forceinline__ void arena_start_game(const ArenaArrays& a, int g, in
 
 /* Start of a round of n_games episodes recorded in rows [row0, row0 + n_games): the first
  * min(G, n_games) start now, the rest when a slot frees up (k_arena_refill). */
-__global__ void __launch_bounds__(256) k_arena_begin(const ArenaArrays a, int row0, int n_games,
-                                                     const long long* seeds, int episode, float* obs_out) {
+__global__ void __launch_bounds__(256) k_arena_rows(const ArenaArrays a, int vrow0, int n_games,
+                                                    const long long* seeds, int episode, double temperature) {
+    /* queue entries of n_games games from virtual row vrow0 on */
     const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     for (int i = tid; i < n_games; i += nth) {
-        a.row_seed[row0 + i] = seeds[i];
-        a.length[row0 + i] = 0;
+        const int row = (vrow0 + i) % a.n_rows;
+        a.row_seed[row] = seeds[i];
+        a.length[row] = 0;
+        a.row_episode[row] = episode;
+        a.row_temp[row] = temperature;
     }
+}
+
+/* after k_arena_rows: reset the queue to [row0, row0 + n_games) and start its first min(G, n_games) games */
+__global__ void __launch_bounds__(256) k_arena_begin(const ArenaArrays a, int row0, int n_games, int episode,
+                                                     float* obs_out) {
+    const int tid = blockIdx.x * blockDim.x + threadIdx.x, nth = gridDim.x * blockDim.x;
     if (tid == 0) {
-        a.ctl[0] = row0 + (n_games < a.G ? n_games : a.G);
+        const int started = n_games < a.G ? n_games : a.G;
+        a.ctl[0] = row0 + started;
         a.ctl[1] = row0 + n_games;
+        a.ctl[2] = row0; /* nothing has finished yet */
     }
     for (int g = tid; g < a.G; g += nth) {
         if (g < n_games) {
-            arena_start_game(a, g, row0 + g, seeds[g], episode, obs_out);
+            arena_start_game(a, g, row0 + g, obs_out);
         } else {
             a.alive[g] = 0;
             a.episode[g] = episode;
         }
     }
+}
+
+/* mzs_arena_enqueue: the rows were written by k_arena_rows; move the queue's end */
+__global__ void k_arena_enqueue(const ArenaArrays a, int n_games) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) a.ctl[1] += n_games;
 }
 
 /* One move of every live game: store_search_statistics (game.py:154-168), policy_step
@@ -114,6 +138,8 @@ __global__ void __launch_bounds__(256) k_arena_step(const ArenaArrays a, const i
     const double p0 = from_prior ? pr[0] : (double)v[0];
     double tsum = 0.0;
     bool all_equal = true;
+    const double rt = a.row_temp[row];
+    if (rt == rt) temperature = rt; /* the game's own temperature (mzs_arena_enqueue); NaN: this move's argument */
     for (int i = 0; i < A; ++i) {
         const double pi = from_prior ? pr[i] : (double)v[i];
         tsum += mzs_policy_power(pi, temperature);
@@ -179,16 +205,27 @@ __global__ void __launch_bounds__(kRefillThreads) k_arena_refill(const ArenaArra
         part[tid] += v;
         __syncthreads();
     }
-    int k = next + part[tid] - dead; /* row of this thread's first free slot */
+    int k = next + part[tid] - dead; /* virtual row of this thread's first free slot */
     const int total_dead = part[kRefillThreads - 1];
+    int oldest = 0x7fffffff; /* oldest game still (or newly) running among this thread's slots */
     for (int g = g0; g < g1; ++g) {
-        if (a.alive[g]) continue;
-        if (k < end) arena_start_game(a, g, k, a.row_seed[k], a.episode[g], obs_io);
-        ++k;
+        if (!a.alive[g]) {
+            if (k < end) arena_start_game(a, g, k, obs_io);
+            ++k;
+        }
+        if (a.alive[g]) oldest = a.vrow[g] < oldest ? a.vrow[g] : oldest;
+    }
+    __syncthreads();
+    part[tid] = oldest;
+    __syncthreads();
+    for (int off = kRefillThreads / 2; off > 0; off >>= 1) {
+        if (tid < off) part[tid] = part[tid + off] < part[tid] ? part[tid + off] : part[tid];
+        __syncthreads();
     }
     if (tid == 0) {
         const int started = next + total_dead <= end ? total_dead : end - next;
         a.ctl[0] = next + started;
+        a.ctl[2] = part[0] < next + started ? part[0] : next + started;
         *alive_count = a.G - total_dead + started;
     }
 }

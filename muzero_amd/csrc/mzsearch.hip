@@ -1730,6 +1730,7 @@ int mzs_fill_streams(mzs_handle* h, int32_t n_games, int32_t num_simulations, in
 struct mzs_arena {
     mzs_arena_config cfg;
     ArenaArrays a;
+    long long queued_end = -1; /* host mirror of ctl[1] (virtual row behind the last queued game) */
     int* alive_count_dev = nullptr;
     std::vector<void*> allocs;
 };
@@ -1764,7 +1765,9 @@ int mzs_arena_create(const mzs_arena_config* cfg, mzs_arena** out) {
     if ((rc = arena_alloc(ar, &a.state, G * 4)) || (rc = arena_alloc(ar, &a.alive, G)) ||
         (rc = arena_alloc(ar, &a.row, G)) || (rc = arena_alloc(ar, &a.seed, G)) ||
         (rc = arena_alloc(ar, &a.episode, G)) || (rc = arena_alloc(ar, &a.stream_seed, G)) ||
-        (rc = arena_alloc(ar, &a.ctl, 2)) || (rc = arena_alloc(ar, &a.row_seed, R)) ||
+        (rc = arena_alloc(ar, &a.ctl, 4)) || (rc = arena_alloc(ar, &a.row_seed, R)) ||
+        (rc = arena_alloc(ar, &a.vrow, G)) || (rc = arena_alloc(ar, &a.row_episode, R)) ||
+        (rc = arena_alloc(ar, &a.row_temp, R)) ||
         (rc = arena_alloc(ar, &a.length, R)) ||
         (rc = arena_alloc(ar, &a.obs, R * T * a.obs_dim)) || (rc = arena_alloc(ar, &a.action, R * T)) ||
         (rc = arena_alloc(ar, &a.reward, R * T)) || (rc = arena_alloc(ar, &a.root_value, R * T)) ||
@@ -1792,10 +1795,29 @@ int mzs_arena_begin(mzs_arena* ar, int32_t row0, int32_t n_games, const int64_t*
     if (n_games < 1 || row0 < 0 || row0 + n_games > ar->a.n_rows)
         return fail(MZS_E_ARG, "rows [row0, row0 + n_games) out of range");
     HIP_TRY(hipSetDevice(ar->cfg.device));
-    const int n = n_games > ar->a.G ? n_games : ar->a.G;
-    hipLaunchKernelGGL(k_arena_begin, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       ar->a, row0, n_games, reinterpret_cast<const long long*>(seeds_dev), episode, obs_dev);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_arena_rows, dim3((n_games + 255) / 256), dim3(256), 0, st, ar->a, row0, n_games,
+                       reinterpret_cast<const long long*>(seeds_dev), episode, (double)NAN);
+    hipLaunchKernelGGL(k_arena_begin, dim3((ar->a.G + 255) / 256), dim3(256), 0, st, ar->a, row0, n_games, episode,
+                       obs_dev);
     HIP_TRY(hipGetLastError());
+    ar->queued_end = (long long)row0 + n_games;
+    return MZS_OK;
+}
+
+int mzs_arena_enqueue(mzs_arena* ar, int32_t n_games, const int64_t* seeds_dev, int32_t episode, double temperature,
+                      void* stream) {
+    if (!ar || !seeds_dev) return fail(MZS_E_ARG, "null argument");
+    if (n_games < 1 || n_games > ar->a.n_rows) return fail(MZS_E_ARG, "n_games must be in [1, n_rows]");
+    if (ar->queued_end < 0) return fail(MZS_E_STATE, "mzs_arena_begin has not been called");
+    if (ar->queued_end + n_games > 0x7fffffffLL) return fail(MZS_E_ARG, "virtual row counter would overflow");
+    HIP_TRY(hipSetDevice(ar->cfg.device));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(k_arena_rows, dim3((n_games + 255) / 256), dim3(256), 0, st, ar->a, (int)ar->queued_end, n_games,
+                       reinterpret_cast<const long long*>(seeds_dev), episode, temperature);
+    hipLaunchKernelGGL(k_arena_enqueue, dim3(1), dim3(64), 0, st, ar->a, n_games);
+    HIP_TRY(hipGetLastError());
+    ar->queued_end += n_games;
     return MZS_OK;
 }
 
@@ -1889,6 +1911,7 @@ void* mzs_arena_array(mzs_arena* ar, int32_t which) {
         case MZS_ARENA_STATE: return ar->a.state;
         case MZS_ARENA_STREAM_SEED: return ar->a.stream_seed;
         case MZS_ARENA_SLOT_ROW: return ar->a.row;
+        case MZS_ARENA_QUEUE: return ar->a.ctl;
         default: return nullptr;
     }
 }

@@ -116,7 +116,10 @@ void mzo_store_policy(int32_t A, const int32_t* visits, const double* prior, flo
 int32_t mzo_policy_action(int32_t A, const double* policy, double temperature, double u);
 double mzo_cartpole_step(double* state4, int32_t action, int32_t* terminated); /* returns the reward */
 typedef struct mzo_arena { /* arrays owned by the caller (oracle/mz_oracle.py) */
-    int32_t G, n_rows, T, A, episode, next_row, row_end;
+    /* next_row / row_end / done_upto count VIRTUAL rows (never wrap; trajectory row = v % n_rows):
+     * [next_row, row_end) are the queued games no slot has started yet, every game below done_upto
+     * has finished */
+    int32_t G, n_rows, T, A, episode, next_row, row_end, done_upto;
     double* state;        /* [G][4] */
     int32_t* alive;       /* [G] */
     int32_t* row;         /* [G] */
@@ -129,8 +132,13 @@ typedef struct mzo_arena { /* arrays owned by the caller (oracle/mz_oracle.py) *
     float* traj_reward;   /* [n_rows][T] */
     float* traj_root;     /* [n_rows][T] */
     float* traj_policy;   /* [n_rows][T][A] */
+    int32_t* row_episode; /* [n_rows] random-number key of the row's game (the round it was queued for) */
+    double* row_temp;     /* [n_rows] action-selection temperature of the row's game; NaN: the step's argument */
+    int32_t* vrow;        /* [G] virtual row of the slot's game */
 } mzo_arena;
 void mzo_arena_begin(mzo_arena* ar, int32_t row0, int32_t n_games, const int64_t* seeds, int32_t episode);
+/* mzs_arena_enqueue: n_games more games behind the queue's end */
+void mzo_arena_enqueue(mzo_arena* ar, int32_t n_games, const int64_t* seeds, int32_t episode, double temperature);
 int32_t mzo_arena_step(mzo_arena* ar, const int32_t* visits, const float* root_value, const double* root_prior,
                        double temperature, int32_t from_prior);
 void mzo_make_priority(int32_t n_rows, int32_t T, const int32_t* length, const float* traj_reward,

@@ -268,9 +268,10 @@ def cartpole_step(state, action):
 
 
 class _Arena(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("G", "n_rows", "T", "A", "episode", "next_row", "row_end")] + \
+    _fields_ = [(n, C.c_int32) for n in ("G", "n_rows", "T", "A", "episode", "next_row", "row_end", "done_upto")] + \
                [(n, C.c_void_p) for n in ("state", "alive", "row", "stream_seed", "obs", "row_seed", "length",
-                                          "traj_obs", "traj_action", "traj_reward", "traj_root", "traj_policy")]
+                                          "traj_obs", "traj_action", "traj_reward", "traj_root", "traj_policy",
+                                          "row_episode", "row_temp", "vrow")]
 
 
 class ArenaOracle:
@@ -291,15 +292,33 @@ class ArenaOracle:
         self.traj_reward = np.zeros((R, T), np.float32)
         self.traj_root = np.zeros((R, T), np.float32)
         self.traj_policy = np.zeros((R, T, A), np.float32)
-        self.c = _Arena(G, R, T, A, 0, 0, 0, *(a.ctypes.data for a in (
+        self.row_episode = np.zeros(R, np.int32)
+        self.row_temp = np.full(R, np.nan, np.float64)
+        self.vrow = np.zeros(G, np.int32)
+        self.c = _Arena(G, R, T, A, 0, 0, 0, 0, *(a.ctypes.data for a in (
             self.state, self.alive, self.row, self.stream_seed, self.obs, self.row_seed, self.length,
-            self.traj_obs, self.traj_action, self.traj_reward, self.traj_root, self.traj_policy)))
+            self.traj_obs, self.traj_action, self.traj_reward, self.traj_root, self.traj_policy,
+            self.row_episode, self.row_temp, self.vrow)))
 
     def begin(self, seeds, episode, row0=0):
         seeds = np.ascontiguousarray(seeds, np.int64)
         assert row0 + len(seeds) <= self.n_rows
         lib().mzo_arena_begin(C.byref(self.c), C.c_int32(row0), C.c_int32(len(seeds)), _p(seeds), C.c_int32(episode))
         return self.obs
+
+    def enqueue(self, seeds, episode, temperature=float("nan")):
+        """More games behind the queue's end (mzs_arena_enqueue); rows wrap modulo n_rows."""
+        seeds = np.ascontiguousarray(seeds, np.int64)
+        lib().mzo_arena_enqueue(C.byref(self.c), C.c_int32(len(seeds)), _p(seeds), C.c_int32(episode),
+                                C.c_double(temperature))
+
+    @property
+    def done_upto(self):
+        return int(self.c.done_upto)
+
+    @property
+    def queue(self):
+        return int(self.c.next_row), int(self.c.row_end)
 
     def step(self, visits, root_value, root_prior, temperature, from_prior=False):
         v = np.ascontiguousarray(visits, np.int32)

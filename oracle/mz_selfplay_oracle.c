@@ -11,6 +11,7 @@
  * the build container with torchvision stubbed).  The CartPole physics and the counter-based
  * random numbers live in include/mzs_env.h (not in the reference; physics parity unpinned).
  */
+#include <math.h>
 #include <string.h>
 
 #include "mz_oracle.h"
@@ -75,15 +76,25 @@ static int64_t stream_seed(int64_t seed, int32_t episode, int32_t move) {
     return (seed + 0x9E3779B1LL * (int64_t)(move + 1) + 0x85EBCA77LL * (int64_t)episode) & 0xFFFFFFFFLL;
 }
 
-static void start_game(mzo_arena* ar, int g, int row) {
+static void start_game(mzo_arena* ar, int g, int vrow) {
+    const int row = vrow % ar->n_rows;
     mzs_cartpole st;
-    mzs_cartpole_reset(&st, (uint64_t)ar->row_seed[row], (uint32_t)ar->episode);
+    mzs_cartpole_reset(&st, (uint64_t)ar->row_seed[row], (uint32_t)ar->row_episode[row]);
     double* s = ar->state + (size_t)g * 4;
     s[0] = st.x, s[1] = st.x_dot, s[2] = st.theta, s[3] = st.theta_dot;
     for (int j = 0; j < 4; ++j) ar->obs[(size_t)g * 4 + j] = (float)s[j];
     ar->alive[g] = 1;
     ar->row[g] = row;
-    ar->stream_seed[g] = stream_seed(ar->row_seed[row], ar->episode, 0);
+    ar->vrow[g] = vrow;
+    ar->stream_seed[g] = stream_seed(ar->row_seed[row], ar->row_episode[row], 0);
+}
+
+/* every game below this virtual row has finished: the queue's head, or the oldest game still running */
+static void update_done(mzo_arena* ar) {
+    int d = ar->next_row;
+    for (int g = 0; g < ar->G; ++g)
+        if (ar->alive[g] && ar->vrow[g] < d) d = ar->vrow[g];
+    ar->done_upto = d;
 }
 
 /* a round of n_games episodes in rows [row0, row0 + n_games): the first min(G, n_games) start now */
@@ -92,6 +103,8 @@ void mzo_arena_begin(mzo_arena* ar, int32_t row0, int32_t n_games, const int64_t
     for (int i = 0; i < n_games; ++i) {
         ar->row_seed[row0 + i] = seeds[i];
         ar->length[row0 + i] = 0;
+        ar->row_episode[row0 + i] = episode;
+        ar->row_temp[row0 + i] = NAN;
     }
     ar->next_row = row0 + (n_games < ar->G ? n_games : ar->G);
     ar->row_end = row0 + n_games;
@@ -101,6 +114,19 @@ void mzo_arena_begin(mzo_arena* ar, int32_t row0, int32_t n_games, const int64_t
         else
             ar->alive[g] = 0;
     }
+    update_done(ar);
+}
+
+/* more games behind the queue's end (they start as slots free up, from the next step on) */
+void mzo_arena_enqueue(mzo_arena* ar, int32_t n_games, const int64_t* seeds, int32_t episode, double temperature) {
+    for (int i = 0; i < n_games; ++i) {
+        const int row = (ar->row_end + i) % ar->n_rows;
+        ar->row_seed[row] = seeds[i];
+        ar->length[row] = 0;
+        ar->row_episode[row] = episode;
+        ar->row_temp[row] = temperature;
+    }
+    ar->row_end += n_games;
 }
 
 /* one move of every live slot, then free slots take the next unplayed games in slot order;
@@ -114,10 +140,11 @@ int32_t mzo_arena_step(mzo_arena* ar, const int32_t* visits, const float* root_v
         const int32_t* v = visits + (size_t)g * A;
         mzo_store_policy(A, v, root_prior + (size_t)g * A, ar->traj_policy + ((size_t)row * T + t) * A);
         ar->traj_root[(size_t)row * T + t] = root_value[g];
-        const double u = mzs_uniform01((uint64_t)ar->row_seed[row], (uint32_t)ar->episode, (uint32_t)t, MZS_RNG_ACTION);
+        const double u = mzs_uniform01((uint64_t)ar->row_seed[row], (uint32_t)ar->row_episode[row], (uint32_t)t, MZS_RNG_ACTION);
         double pv[64];
         for (int i = 0; i < A; ++i) pv[i] = from_prior ? root_prior[(size_t)g * A + i] : (double)v[i];
-        const int act = mzo_policy_action(A, pv, temperature, u);
+        const double temp = isnan(ar->row_temp[row]) ? temperature : ar->row_temp[row];
+        const int act = mzo_policy_action(A, pv, temp, u);
         double* s = ar->state + (size_t)g * 4;
         mzs_cartpole st = {s[0], s[1], s[2], s[3]};
         const int terminated = mzs_cartpole_step(&st, act);
@@ -130,13 +157,14 @@ int32_t mzo_arena_step(mzo_arena* ar, const int32_t* visits, const float* root_v
         ar->traj_reward[(size_t)row * T + t] = 1.0f;
         ar->length[row] = t + 1;
         ar->alive[g] = !terminated && t + 1 < T; /* self_play.py:62 */
-        ar->stream_seed[g] = stream_seed(ar->row_seed[row], ar->episode, t + 1);
+        ar->stream_seed[g] = stream_seed(ar->row_seed[row], ar->row_episode[row], t + 1);
     }
     int32_t n_alive = 0;
     for (int g = 0; g < ar->G; ++g) {
         if (!ar->alive[g] && ar->next_row < ar->row_end) start_game(ar, g, ar->next_row++);
         n_alive += ar->alive[g];
     }
+    update_done(ar);
     return n_alive;
 }
 

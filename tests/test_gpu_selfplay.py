@@ -85,6 +85,87 @@ def test_arena_step_vs_oracle(temperature):
     ar.close(), eng.close()
 
 
+def test_arena_rolling_queue_vs_oracle():
+    """mzs_arena_enqueue: three rounds queued one ahead of each other, rows wrapping round the ring,
+    each round with its own temperature and random-number key; slots freed by round k's last games
+    start round k + 1's — slot rows, stream seeds, queue state (next, end, done_upto) and every
+    trajectory array equal the oracle's after every move."""
+    import torch
+    from muzero_amd.selfplay import Arena
+    from oracle import mz_oracle as mzo
+    G, T, N = 64, 20, 150
+    R = 3 * N                                   # ring: round 3 reuses round 0's rows
+    eng, dims, _ = make_engine(G, 0)
+    ar = Arena(eng, G, R, T)
+    orc = mzo.ArenaOracle(G, T, n_rows=R)
+    seeds = lambda k: np.arange(N, dtype=np.int64) * 104729 + 13 * k + 1   # noqa: E731
+    temps = [1.0, 0.5, 0.0, 0.25]
+    obs = ar.begin(0, seeds(0), episode=0)
+    orc.begin(seeds(0), 0, row0=0)
+    rs = np.random.RandomState(11)
+    moves = full = 0
+    for k in range(4):
+        if k < 3:                               # keep one round ahead
+            ar.enqueue(seeds(k + 1), k + 1, temps[k + 1])
+            orc.enqueue(seeds(k + 1), k + 1, temps[k + 1])
+        while orc.done_upto < (k + 1) * N:
+            (v, rv, pr), res = fake_results(rs, G, 2, eng.device)
+            ar.step(temps[0], res, num_simulations=50)          # rows of begin(): NaN -> this argument
+            n_alive = orc.step(v, rv, pr, temps[0])
+            torch.cuda.synchronize()
+            moves += 1
+            full += n_alive == G
+            assert int(ar.alive_count.item()) == n_alive
+            assert ar.queue_state() == (*orc.queue, orc.done_upto)
+            live = orc.alive == 1
+            assert np.array_equal(host(ar.arrays["alive"]), orc.alive)
+            assert np.array_equal(host(ar.arrays["slot_row"])[live], orc.row[live])
+            assert np.array_equal(host(ar.arrays["stream_seed"])[live], orc.stream_seed[live])
+            assert np.array_equal(host(obs), orc.obs)
+        got = arena_host(ar)
+        blk = slice((k % 3) * N, (k % 3 + 1) * N)               # round k's rows are complete now
+        assert np.all(orc.length[blk] >= 1)
+        for name, w in (("length", orc.length), ("obs", orc.traj_obs), ("action", orc.traj_action),
+                        ("root_value", orc.traj_root), ("policy", orc.traj_policy)):
+            assert np.array_equal(got[name][blk], w[blk]), (k, name)
+    assert orc.done_upto == 4 * N and n_alive == 0
+    # the point of the queue: except for the last round's tail the slots were all busy
+    assert full / moves > 0.7
+    ar.close(), eng.close()
+
+
+def test_rolling_learning_cycle_keeps_slots_busy():
+    """SelfPlay(rolling=True) end to end with the real search: rewards / losses finite, the store
+    follows the window rule, and the slots' utilisation over the run beats the synchronous loop's."""
+    from muzero_amd.selfplay import Arena, ReplayStore, SelfPlay
+    from muzero_amd.train import Trainer
+    util = {}
+    for rolling in (False, True):
+        G, T, S, B, K, td, N = 128, 48, 10, 64, 5, 10, 512
+        eng, dims, blob = make_engine(G, S)
+        tr = Trainer(eng, K, B, "adam", 1e-3)
+        store = ReplayStore(window_size=2 * N, batch_size=B, num_unroll=K, td_steps=td, discount=0.997)
+        ar = Arena(eng, G, (5 if rolling else 4) * N, T)
+        np.random.seed(0)
+        loop = SelfPlay(None, eng, tr, ar, store, S, games_per_iteration=N, seed=42, rolling=rolling)
+        lock = moves = 0
+        rewards = []
+        for ep in range(5):
+            r = loop.play(1.0, 1.0 if ep < 4 else None)
+            rewards.append(float(r.mean()))
+            lock += loop.lockstep_moves
+            moves += int(r.sum())
+            for _ in range(2):
+                assert np.isfinite(float(loop.train_step().item()))
+        util[rolling] = moves / (lock * G)
+        assert all(1 <= x <= T for x in rewards) and len(store) == 2 * N + 1
+        length = host(ar.arrays["length"])
+        assert all(length[r] == n for r, n in zip(store.rows, store.lengths))
+        ar.close(), eng.close()
+    print(f"\nslot utilisation: synchronous {util[False]:.2f}, rolling {util[True]:.2f}")
+    assert util[True] > util[False] + 0.05 and util[True] > 0.8
+
+
 @pytest.mark.parametrize("temperature", [0.0, 1.0])
 def test_arena_step_zero_simulations(temperature):
     """number_of_mcts_simulation = 0 (experiment_130..133 configs): policy_step gets the root priors

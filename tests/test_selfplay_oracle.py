@@ -284,3 +284,39 @@ def test_arena_oracle_refills_free_slots_in_order():
     st = solo.state[0].copy()
     s2, _, _ = mzo.cartpole_step(st, int(ar.traj_action[9, 0]))
     assert np.array_equal(s2.astype(np.float32), ar.traj_obs[9, 0]) and np.all(np.abs(first) <= 0.05)
+
+
+def test_oracle_rolling_queue_semantics():
+    """mzo_arena_enqueue (the CPU statement of mzs_arena_enqueue): a game's trajectory depends on its
+    (seed, round key, temperature) only — queued behind another round and started in whatever slot
+    frees up, it records exactly what it records when its round is played on its own."""
+    from oracle import mz_oracle as mzo
+    G, T, N = 16, 25, 60
+
+    def fake(ar):
+        v = np.stack([(ar.obs[:, 2] > 0) * 30 + 10, (ar.obs[:, 2] <= 0) * 30 + 10], 1).astype(np.int32)
+        return v, ar.obs[:, 0].copy(), np.full((ar.G, 2), 0.5)
+
+    seeds = [np.arange(N, dtype=np.int64) * 31 + 7 + 1000 * k for k in range(3)]
+    temps = [1.0, 0.0, 0.5]
+    roll = mzo.ArenaOracle(G, T, n_rows=3 * N)
+    roll.begin(seeds[0], 0)
+    for k in (1, 2):
+        roll.enqueue(seeds[k], k, temps[k])
+    lock = 0
+    while True:
+        lock += 1
+        if roll.step(*fake(roll), temps[0]) == 0:
+            break
+    assert roll.done_upto == 3 * N and roll.queue == (3 * N, 3 * N)
+    total = int(roll.length.sum())
+    for k in range(3):                              # each round alone, on a different slot count
+        solo = mzo.ArenaOracle(7, T, n_rows=N)
+        solo.begin(seeds[k], k)
+        while solo.step(*fake(solo), temps[k]) != 0:
+            pass
+        blk = slice(k * N, (k + 1) * N)
+        assert np.array_equal(solo.length, roll.length[blk])
+        assert np.array_equal(solo.traj_action, roll.traj_action[blk])
+        assert np.array_equal(solo.traj_obs, roll.traj_obs[blk])
+    assert total / (lock * G) > 0.85                # one queue, one tail: the slots stayed busy
