@@ -202,7 +202,7 @@ class TrainBatch(C.Structure):
 def blob_size(d):
     from muzero_amd.model import blob_layout
     return sum(int(np.prod(shp)) for _, shp in
-               blob_layout(d.obs_dim, d.n_actions, d.state_dim, d.hidden_dim, d.n_mid_layers))
+               blob_layout(d.obs_dim, d.n_actions, d.state_dim, d.hidden_dim, d.n_mid_layers, d.model_kind))
 
 
 def train_grad(d, blob, obs, actions, target_value, target_reward, target_policy, is_ratio=None,

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from test_train_oracle import GRAD_REL, LOSS_REL, TRAIN_FIXTURES, check_against_fixture, step_inputs
+from test_train_oracle import GRAD_REL, LOSS_REL, MLP_TRAIN_FIXTURES as TRAIN_FIXTURES, check_against_fixture, step_inputs
 
 pytestmark = pytest.mark.gpu
 

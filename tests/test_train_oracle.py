@@ -6,8 +6,11 @@ import pytest
 
 from conftest import load_golden
 
-TRAIN_FIXTURES = ["train_tag123_K5_B128.npz", "train_tag133_K3_B32.npz", "train_synA4_K4_B16.npz",
-                  "train_init_K10_B64.npz"]
+MLP_TRAIN_FIXTURES = ["train_tag123_K5_B128.npz", "train_tag133_K3_B32.npz", "train_synA4_K4_B16.npz",
+                      "train_init_K10_B64.npz"]
+# 'lstm_model' (tests/golden/make_lstm_train_fixtures.py): every head's LSTM runs along the batch axis
+LSTM_TRAIN_FIXTURES = ["train_lstmA_K5_B128.npz", "train_lstmB_K3_B32.npz", "train_lstmC_K4_B48.npz"]
+TRAIN_FIXTURES = MLP_TRAIN_FIXTURES + LSTM_TRAIN_FIXTURES
 # fp32 tolerances of the training path (north_star: 1e-5 relative in fp32)
 LOSS_REL = 1e-5          # every loss term and loss_nn
 GRAD_REL = 1e-5          # max |g - g_ref| <= GRAD_REL * max |g_ref| per step
@@ -39,8 +42,11 @@ def check_against_fixture(fx, s, out, blob_after=None, lr=None):
     if blob_after is not None:
         ref = fx[f"s{s}_blob"]
         # Adam's first steps move every weight by ~lr * g / (|g| + eps): where |g| is tiny the update
-        # direction is ill-conditioned, so compare in units of the step size
-        assert np.abs(blob_after - ref).max() <= 2e-3 * lr + 1e-6
+        # direction is ill-conditioned, so compare in units of the step size.  The LSTM fixtures hold
+        # gradient entries of ~1e-9, a tenth of Adam's eps (far ends of the batch-axis recurrence):
+        # there an error of 1e-7 * max|g| already turns the step by half a percent
+        frac = 1e-2 if len(fx["dims"]) > 5 and int(fx["dims"][5]) == 1 else 2e-3
+        assert np.abs(blob_after - ref).max() <= frac * lr + 1e-6
 
 
 @pytest.mark.parametrize("fname", TRAIN_FIXTURES)
