@@ -440,8 +440,9 @@ __global__ void __launch_bounds__(256) k_train_apply(const ApplyParams p) {
     }
     p.blob[i] = w;
     const int si = p.store_index[i], so = si & 0x3fffffff;
+    if (si == -1) return; /* not in the store: a search never reads it (LSTM W_hh, forget-gate rows) */
     p.store[so] = w;
-    if (p.store16) p.store16[so] = (si >> 30) ? w : mzs_bf16_round(w);
+    if (p.store16) p.store16[so] = ((si >> 30) & 1) ? w : mzs_bf16_round(w);
 }
 
 }  // namespace mzs

@@ -24,6 +24,7 @@
 #include "mzs_quadw.h"
 #include "mzs_quadl.h"
 #include "mzs_train.h"
+#include "mzs_train_lstm.h"
 #include "mzs_selfplay.h"
 #include "mzs_replay.h"
 
@@ -634,6 +635,7 @@ struct mzs_handle {
     float* adam_m_dev = nullptr;
     float* adam_v_dev = nullptr;
     double* wgrad_partial_dev = nullptr;
+    LstmTrainParams lstm_train;    /* 'lstm_model': tape layout and descriptor tables of mzs_train_create */
     size_t w_floats = 0;
     bool have_weights = false;
     int n_nodes_max = 0;
@@ -721,14 +723,18 @@ LstmHead describe_lstm_head(StoreBuilder* sb, int lin_rows, int lin_k, int H, in
 void fill_lstm_head(StoreBuilder* sb, const LstmHead& hd, const float* B, const mzs_lstm_head_offsets& o, int H,
                     int n_layers) {
     const int n = hd.n_out;
-    sb->fill(hd.lin, B + o.lin_w, B + o.lin_b, H, o.in_dim, o.in_dim, 0);
+    sb->fill_at(hd.lin, B, o.lin_w, o.lin_b, H, o.in_dim, o.in_dim, 0);
     for (int l = 0; l < n_layers; ++l) {
         const int in_l = l == 0 ? H : n;
         const int gate_row[3] = {0, 2, 3}; /* torch rows i, f, g, o: f never contributes (c0 = 0) */
         for (int q = 0; q < 3; ++q) {
             const size_t r0 = (size_t)gate_row[q] * n;
-            sb->fill(hd.gate[l], B + o.w_ih[l] + r0 * in_l, B + o.b_ih[l] + r0, n, in_l, in_l, q * hd.out_pad);
-            for (int j = 0; j < n; ++j) sb->data[(size_t)hd.bhh_off[l] + q * hd.out_pad + j] = B[o.b_hh[l] + r0 + j];
+            sb->fill_at(hd.gate[l], B, o.w_ih[l] + r0 * in_l, o.b_ih[l] + r0, n, in_l, in_l, q * hd.out_pad);
+            for (int j = 0; j < n; ++j) {
+                const size_t so = (size_t)hd.bhh_off[l] + q * hd.out_pad + j;
+                sb->data[so] = B[o.b_hh[l] + r0 + j];
+                if (!sb->index.empty()) sb->index[o.b_hh[l] + r0 + j] = (int)so | kStoreBiasFlag;
+            }
         }
     }
 }
@@ -1225,12 +1231,15 @@ int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats) {
     describe_model(d, &m, &sb);
     if (d.model_kind == MZS_MODEL_LSTM) {
         const mzs_lstm_offsets lo = mzs_lstm_layout(&d);
-        sb.fill(m.r_in, B + lo.r_w, B + lo.r_b, Sd, ob, ob, 0);
+        /* W_hh and the forget-gate rows are not in the store (a search never reads them): index -1 */
+        sb.index.assign(n_floats, -1);
+        sb.fill_at(m.r_in, B, lo.r_w, lo.r_b, Sd, ob, ob, 0);
         fill_lstm_head(&sb, m.l_rew, B, lo.rew, H, d.n_mid_layers);
         fill_lstm_head(&sb, m.l_st, B, lo.st, H, d.n_mid_layers);
         fill_lstm_head(&sb, m.l_pol, B, lo.pol, H, d.n_mid_layers);
         fill_lstm_head(&sb, m.l_val, B, lo.val, H, d.n_mid_layers);
         HIP_TRY(hipMemcpy(h->blob_dev, B, n_floats * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->store_index_dev, sb.index.data(), n_floats * sizeof(int), hipMemcpyHostToDevice));
         HIP_TRY(hipMemcpy(h->w_dev, sb.data.data(), sb.data.size() * sizeof(float), hipMemcpyHostToDevice));
         if (h->w_search_dev != h->w_dev) {
             const std::vector<float> r = sb.rounded_bf16();
@@ -1507,17 +1516,191 @@ static void fill_tensor_descs(const mzs_dims& d, const TapeLayout& t, int K, Ten
     set(10, o.p_val_w, o.p_val_b, S, H, pb + t.p_T + L * HP, pb + t.p_dval, K, t.p_stride, 1, 0);
 }
 
+/* 'lstm_model': tape layout (rows of max_batch capacity) and the gradient descriptors of every
+ * parameter tensor (mzs_train_lstm.h).  Host vectors are uploaded once by mzs_train_create. */
+struct LstmTrainPlan {
+    LstmTrainParams p;
+    std::vector<LstmGradDesc> desc;
+    std::vector<int> param_desc;
+    size_t tape_floats;
+};
+
+static LstmTrainPlan make_lstm_train_plan(const mzs_dims& d, int K, int Bcap) {
+    LstmTrainPlan pl;
+    LstmTrainParams& p = pl.p;
+    std::memset(&p, 0, sizeof p);
+    const mzs_lstm_offsets lo = mzs_lstm_layout(&d);
+    const int H = d.hidden_dim, Sd = d.state_dim, A = d.n_actions, L = d.n_mid_layers, ob = d.obs_dim;
+    p.Bcap = Bcap, p.K = K, p.L = L, p.H = H, p.Sd = Sd, p.A = A, p.obs_dim = ob;
+    p.n_params = (int)lo.total;
+    p.r_w = (int)lo.r_w, p.r_b = (int)lo.r_b;
+    long long off = 0;
+    const auto take = [&](long long n) {
+        const long long at = off;
+        off += (n + 63) / 64 * 64;
+        return at;
+    };
+    p.hstate = take((long long)K * Bcap * Sd);
+    p.gh = take((long long)K * Bcap * Sd);
+    const mzs_lstm_head_offsets* src[4] = {&lo.rew, &lo.st, &lo.pol, &lo.val};
+    for (int hd = 0; hd < 4; ++hd) {
+        LstmTrainHead& t = p.head[hd];
+        const mzs_lstm_head_offsets& o = *src[hd];
+        const int n = o.out_dim;
+        t.lin_w = (int)o.lin_w, t.lin_b = (int)o.lin_b, t.in_dim = o.in_dim, t.n = n;
+        t.wt_lin = take((long long)o.in_dim * H);
+        int r = 0;
+        const auto field = [&](int rows_of) {
+            const int at = r;
+            r += (Bcap * rows_of + 63) / 64 * 64;
+            return at;
+        };
+        t.u = field(H), t.du = field(H), t.dx = field(Sd), t.dout = field(n);
+        for (int l = 0; l < L; ++l) {
+            t.w_ih[l] = (int)o.w_ih[l], t.w_hh[l] = (int)o.w_hh[l];
+            t.b_ih[l] = (int)o.b_ih[l], t.b_hh[l] = (int)o.b_hh[l];
+            t.wt_ih[l] = take((long long)(l == 0 ? H : n) * 4 * n);
+            t.gates[l] = field(4 * n), t.c[l] = field(n), t.h[l] = field(n), t.dz[l] = field(4 * n),
+            t.dmid[l] = field(n);
+        }
+        t.stride = r;
+        const int n_calls = hd < 2 ? (K > 1 ? K - 1 : 0) : K;
+        t.base = take((long long)n_calls * r);
+    }
+    pl.tape_floats = (size_t)off;
+
+    pl.param_desc.assign(lo.total, -1);
+    const long long hs = (long long)Bcap * Sd;
+    const auto add = [&](LstmGradDesc g) {
+        const int di = (int)pl.desc.size();
+        pl.desc.push_back(g);
+        for (int r = 0; r < g.n_rows; ++r)
+            for (int c = 0; c < (g.n_cols ? g.n_cols : 1); ++c) pl.param_desc[(size_t)g.w_off + (size_t)r * g.ld + c] = di;
+    };
+    const auto weight = [&](int w_off, int ld, int n_rows, int n_cols, long long d_base, long long d_stride, int d_ld,
+                            long long x_base, long long x_stride, int x_ld, int n_calls, int t_shift, int x_src,
+                            int l2) {
+        LstmGradDesc g;
+        g.w_off = w_off, g.ld = ld, g.n_rows = n_rows, g.n_cols = n_cols;
+        g.d_base = d_base, g.d_stride = d_stride, g.x_base = x_base, g.x_stride = x_stride;
+        g.d_ld = d_ld, g.x_ld = x_ld, g.n_calls = n_calls, g.t_shift = t_shift, g.x_src = x_src, g.l2 = l2;
+        add(g);
+    };
+    const auto bias = [&](int b_off, int n_rows, long long d_base, long long d_stride, int d_ld, int n_calls, int l2) {
+        weight(b_off, 1, n_rows, 0, d_base, d_stride, d_ld, 0, 0, 0, n_calls, 0, 0, l2);
+    };
+    /* representation: delta = total gradient of h_0, input = the observation rows; in the l2 term */
+    weight(p.r_w, ob, Sd, ob, p.gh, 0, Sd, 0, 0, ob, 1, 0, 1, 1);
+    bias(p.r_b, Sd, p.gh, 0, Sd, 1, 1);
+    for (int hd = 0; hd < 4; ++hd) {
+        const LstmTrainHead& t = p.head[hd];
+        const int n = t.n, nc = hd < 2 ? (K > 1 ? K - 1 : 0) : K;
+        /* l2 (neural_network_mlp_model.py:280-285): the zip() over the three parameter lists stops after
+         * the representation's two tensors: reward.0 and policy.0 are the only head tensors in it */
+        const int l2 = hd == kHeadRew || hd == kHeadPol;
+        weight(t.lin_w, t.in_dim, H, Sd, t.base + t.du, t.stride, H, p.hstate, hs, Sd, nc, 0, 0, l2);
+        if (hd < 2) weight(t.lin_w + Sd, t.in_dim, H, A, t.base + t.du, t.stride, H, 0, 0, A, nc, 0, 2, l2);
+        bias(t.lin_b, H, t.base + t.du, t.stride, H, nc, l2);
+        for (int l = 0; l < L; ++l) {
+            const int in_l = l == 0 ? H : n;
+            const long long dz = t.base + t.dz[l];
+            const long long x_in = t.base + (l == 0 ? t.u : t.h[l - 1]);
+            weight(t.w_ih[l], in_l, 4 * n, in_l, dz, t.stride, 4 * n, x_in, t.stride, in_l, nc, 0, 0, 0);
+            /* W_hh: input = the layer's own h of the previous row; the next-state head's last layer keeps
+             * its h rows in the hidden-state array (h_{k+1}) */
+            if (hd == kHeadSt && l == L - 1)
+                weight(t.w_hh[l], n, 4 * n, n, dz, t.stride, 4 * n, p.hstate + hs, hs, Sd, nc, 1, 0, 0);
+            else
+                weight(t.w_hh[l], n, 4 * n, n, dz, t.stride, 4 * n, t.base + t.h[l], t.stride, n, nc, 1, 0, 0);
+            bias(t.b_ih[l], 4 * n, dz, t.stride, 4 * n, nc, 0);
+            bias(t.b_hh[l], 4 * n, dz, t.stride, 4 * n, nc, 0);
+        }
+    }
+    p.n_desc = (int)pl.desc.size();
+    return pl;
+}
+
+static int lstm_train_create(mzs_handle* h, int32_t max_batch, int32_t unroll_steps) {
+    const mzs_dims& d = h->cfg.dims;
+    const int n_max = d.state_dim > d.n_actions ? d.state_dim : d.n_actions;
+    if ((size_t)lstm_train_lds_floats(n_max) * sizeof(float) > (size_t)kMaxLdsPerBlock)
+        return fail(MZS_E_ARG, "lstm_model training: packed W_hh does not fit 160 KiB of LDS");
+    LstmTrainPlan pl = make_lstm_train_plan(d, unroll_steps, max_batch);
+    for (size_t i = 0; i < pl.param_desc.size(); ++i)
+        if (pl.param_desc[i] < 0) return fail(MZS_E_STATE, "lstm_model training: a parameter has no gradient descriptor");
+    const size_t n = mzs_blob_total(&d);
+    LstmGradDesc* desc_dev = nullptr;
+    int* param_desc_dev = nullptr;
+    int rc;
+    if ((rc = dev_alloc(h, &h->tape_dev, pl.tape_floats)) ||
+        (rc = dev_alloc(h, &h->loss_buf_dev, (size_t)max_batch * (3 * unroll_steps - 1))) ||
+        (rc = dev_alloc(h, &h->wgrad_partial_dev, (size_t)((max_batch + kLstmWgradRows - 1) / kLstmWgradRows) * n)) ||
+        (rc = dev_alloc(h, &h->adam_m_dev, n)) || (rc = dev_alloc(h, &h->adam_v_dev, n)) ||
+        (rc = dev_alloc(h, &desc_dev, pl.desc.size())) || (rc = dev_alloc(h, &param_desc_dev, pl.param_desc.size())))
+        return rc;
+    HIP_TRY(hipMemcpy(desc_dev, pl.desc.data(), pl.desc.size() * sizeof(LstmGradDesc), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(param_desc_dev, pl.param_desc.data(), pl.param_desc.size() * sizeof(int), hipMemcpyHostToDevice));
+    pl.p.desc = desc_dev;
+    pl.p.param_desc = param_desc_dev;
+    pl.p.tape = h->tape_dev;
+    pl.p.blob = h->blob_dev;
+    pl.p.loss_buf = h->loss_buf_dev;
+    h->lstm_train = pl.p;
+    h->train_batch = max_batch;
+    h->train_K = unroll_steps;
+    h->train_step = 0;
+    return MZS_OK;
+}
+
+/* the six launches of the 'lstm_model' gradient computation (mzs_train_lstm.h) */
+static int lstm_train_grad_launch(mzs_handle* h, int32_t batch, const float* obs_dev, const float* actions_dev,
+                                  const float* target_value_dev, const float* target_reward_dev,
+                                  const float* target_policy_dev, const float* is_ratio_dev, float inv_global_batch,
+                                  float* grad_dev, float* loss_dev, float* priority_dev, hipStream_t st) {
+    LstmTrainParams p = h->lstm_train;
+    p.B = batch;
+    p.inv_batch = inv_global_batch;
+    p.obs = obs_dev, p.actions = actions_dev, p.tv = target_value_dev, p.tr = target_reward_dev;
+    p.tp = target_policy_dev, p.is_ratio = is_ratio_dev;
+    p.priority = priority_dev, p.grad = grad_dev, p.loss_out = loss_dev;
+    const int K = p.K;
+    const int n_max = p.Sd > p.A ? p.Sd : p.A;
+    const size_t shmem = (size_t)lstm_train_lds_floats(n_max) * sizeof(float);
+    if (shmem > 64 * 1024) {
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_chain_fwd),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_heads),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_chain_bwd),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
+    }
+    hipLaunchKernelGGL(k_lstm_prep, dim3(8, 4), dim3(256), 0, st, p);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_lstm_chain_fwd, dim3(1), dim3(kLstmTrainThreads), shmem, st, p);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_lstm_heads, dim3(3 * K - 1), dim3(kLstmTrainThreads), shmem, st, p);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_lstm_chain_bwd, dim3(1), dim3(kLstmTrainThreads), shmem, st, p);
+    HIP_TRY(hipGetLastError());
+    const int n_grad_blocks = (p.n_params + 255) / 256;
+    const int n_chunks = (batch + kLstmWgradRows - 1) / kLstmWgradRows;
+    hipLaunchKernelGGL(k_lstm_wgrad_partial, dim3(n_grad_blocks, n_chunks), dim3(256), 0, st, p, h->wgrad_partial_dev);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(k_lstm_wgrad, dim3(n_grad_blocks + 1), dim3(256), 0, st, p,
+                       (const double*)h->wgrad_partial_dev, n_chunks, n_grad_blocks);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
 int mzs_train_create(mzs_handle* h, int32_t max_batch, int32_t unroll_steps) {
     if (!h) return fail(MZS_E_ARG, "null handle");
     if (max_batch < 1 || unroll_steps < 1) return fail(MZS_E_ARG, "bad batch or unroll length");
     const mzs_dims& d = h->cfg.dims;
-    if (d.model_kind != MZS_MODEL_MLP)
-        return fail(MZS_E_ARG, "training kernels exist for mlp_model only (the reference feeds its LSTM the "
-                               "training batch as one sequence, neural_network_lstm_model.py:35: not built)");
     if (d.state_dim > 64 || d.n_actions > 64)
         return fail(MZS_E_ARG, "training kernels hold one logit per lane: state_dim and n_actions <= 64");
     if (h->tape_dev) return fail(MZS_E_STATE, "mzs_train_create was already called on this handle");
     HIP_TRY(hipSetDevice(h->cfg.device));
+    if (d.model_kind == MZS_MODEL_LSTM) return lstm_train_create(h, max_batch, unroll_steps);
     const TapeLayout t = make_tape_layout(h->model, unroll_steps);
     if ((size_t)t.total * sizeof(float) > (size_t)kMaxLdsPerBlock)
         return fail(MZS_E_ARG, "one sample's unroll does not fit 160 KiB of LDS");
@@ -1593,6 +1776,10 @@ int mzs_train_grad(mzs_handle* h, int32_t batch, const float* obs_dev, const flo
         !grad_dev || !loss_dev || !priority_dev)
         return fail(MZS_E_ARG, "null buffer");
     HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->cfg.dims.model_kind == MZS_MODEL_LSTM)
+        return lstm_train_grad_launch(h, batch, obs_dev, actions_dev, target_value_dev, target_reward_dev,
+                                      target_policy_dev, is_ratio_dev, inv_global_batch, grad_dev, loss_dev,
+                                      priority_dev, static_cast<hipStream_t>(stream));
     return train_grad_launch(h, h->tape_layout, h->train_K, batch, obs_dev, actions_dev, target_value_dev,
                              target_reward_dev, target_policy_dev, is_ratio_dev, inv_global_batch, grad_dev, loss_dev,
                              priority_dev, h->tape_dev, h->loss_buf_dev, h->wgrad_partial_dev,
@@ -1617,7 +1804,9 @@ int mzs_train_grad_static(mzs_handle* h, int32_t batch, int32_t unroll_steps, co
         !grad_dev || !loss_dev || !priority_dev)
         return fail(MZS_E_ARG, "null buffer");
     const mzs_dims& d = h->cfg.dims;
-    if (d.model_kind != MZS_MODEL_MLP) return fail(MZS_E_ARG, "training kernels exist for mlp_model only");
+    if (d.model_kind != MZS_MODEL_MLP)
+        return fail(MZS_E_ARG, "mzs_train_grad_static is built for mlp_model (the lstm_model tape of a whole batch "
+                               "does not fit the static array): use mzs_train_create + mzs_train_grad");
     if (d.state_dim > 64 || d.n_actions > 64)
         return fail(MZS_E_ARG, "training kernels hold one logit per lane: state_dim and n_actions <= 64");
     const TapeLayout tl = make_tape_layout(h->model, unroll_steps);
@@ -1665,7 +1854,7 @@ int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, dou
     p.m = h->adam_m_dev;
     p.v = h->adam_v_dev;
     p.grad = grad_dev;
-    p.n = (int)mzs_blob_layout(&h->cfg.dims).total;
+    p.n = (int)mzs_blob_total(&h->cfg.dims);
     p.optimizer = optimizer;
     p.step = h->train_step;
     const double bc1 = 1.0 - std::pow(0.9, h->train_step), bc2 = 1.0 - std::pow(0.999, h->train_step);

@@ -290,11 +290,11 @@ class Muzero:
         ratio, game positions) as ReplayBuffer.sample_batch returns it (replay_buffer.py:131-166).
         Returns (new_priority: list of K arrays (B, 1), batch_game_position); appends
         [loss_nn, value_0, policy_0, value_1, policy_1, reward_1, ...] to store_loss.
-        With torch.distributed initialised each rank passes its shard of the batch."""
+        With torch.distributed initialised each rank passes its shard of the batch.
+        'lstm_model': every head's nn.LSTM reads the (B, H) batch as ONE sequence of length B
+        (neural_network_lstm_model.py:35), and so do the kernels: the order of the samples matters,
+        and a rank's shard is a sequence of its own."""
         from . import train as tr
-        if self.model_structure != "mlp_model":
-            raise NotImplementedError("train(): kernels exist for 'mlp_model' only (the reference feeds its "
-                                      "LSTM the whole batch as one sequence, neural_network_lstm_model.py:35)")
         if self.loss_type != "general":
             raise NotImplementedError(f"loss_type={self.loss_type!r}: only the 'general' cross-entropy "
                                       "losses every shipped config uses (muzero_model.py:350-361)")

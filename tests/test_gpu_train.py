@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from test_train_oracle import GRAD_REL, LOSS_REL, MLP_TRAIN_FIXTURES as TRAIN_FIXTURES, check_against_fixture, step_inputs
+from test_train_oracle import GRAD_REL, LOSS_REL, TRAIN_FIXTURES, check_against_fixture, step_inputs
 
 pytestmark = pytest.mark.gpu
 
@@ -87,6 +87,87 @@ def test_training_updates_what_the_search_reads():
     assert np.array_equal(pol.view(np.uint32), op.view(np.uint32))
     assert np.array_equal(val.view(np.uint32), ov.view(np.uint32))
     eng.close()
+
+
+def test_lstm_training_updates_what_the_search_reads():
+    """'lstm_model': after mzs_train_apply the device store (Linear, i / g / o gate rows, both bias
+    vectors) holds the new weights — inference == oracle inference with the read-back blob, bit for
+    bit — and a search runs on them."""
+    from oracle import mz_oracle as mzo
+    fx = load_golden("train_lstmB_K3_B32.npz")
+    d = mzo.dims(*fx["dims"])
+    eng, tr = make_trainer(fx)
+    inp = step_inputs(fx, 0)
+    tr.step(inp["obs"], inp["actions"], inp["target_value"], inp["target_reward"], inp["target_policy"],
+            inp["is_ratio"])
+    blob = tr.weights()
+    assert np.count_nonzero(blob != fx["blob0"]) > 0.9 * blob.size
+    hid, pol, val = [t.cpu().numpy() for t in eng.initial_inference(inp["obs"])]
+    oh, op, ov = mzo.initial_inference(d, blob, inp["obs"])
+    assert np.array_equal(hid.view(np.uint32), oh.view(np.uint32))
+    assert np.array_equal(pol.view(np.uint32), op.view(np.uint32))
+    assert np.array_equal(val.view(np.uint32), ov.view(np.uint32))
+    eng.close()
+
+
+def test_lstm_partial_batch_and_repeat():
+    """A batch smaller than max_batch (rows are strided by the capacity, not the batch) and a second
+    call on the same handle: both == the oracle on the same inputs."""
+    from muzero_amd.engine import SearchEngine
+    from muzero_amd.train import Trainer
+    from oracle import mz_oracle as mzo
+    fx = load_golden("train_lstmC_K4_B48.npz")
+    d = mzo.dims(*fx["dims"])
+    eng = SearchEngine(tuple(int(x) for x in fx["dims"]), max_games=1, max_simulations=0)
+    eng.set_weights(fx["blob0"])
+    tr = Trainer(eng, int(fx["K"]), 64, "adam", 0.003, None, 100)
+    inp = step_inputs(fx, 0)
+    for B in (48, 17, 48):
+        sub = dict(obs=inp["obs"][:B], actions=inp["actions"][:, :B], target_value=inp["target_value"][:, :B],
+                   target_reward=inp["target_reward"][:, :B], target_policy=inp["target_policy"][:, :B],
+                   is_ratio=inp["is_ratio"][:B])
+        prio = tr.grad_step(sub["obs"], sub["actions"], sub["target_value"], sub["target_reward"],
+                            sub["target_policy"], sub["is_ratio"])
+        import torch
+        torch.cuda.synchronize()
+        ref = mzo.train_grad(d, fx["blob0"], **sub)
+        loss = tr.loss.cpu().numpy()
+        assert abs(float(loss[-1]) - ref["total_loss"]) <= LOSS_REL * abs(ref["total_loss"])
+        assert np.abs(tr.grad.cpu().numpy() - ref["grad"]).max() <= GRAD_REL * np.abs(ref["grad"]).max()
+        assert np.abs(prio.cpu().numpy() - ref["priority"]).max() <= 1e-5 * (1 + np.abs(ref["priority"]).max())
+    eng.close()
+
+
+def test_muzero_train_drop_in_lstm():
+    """Muzero(model_structure='lstm_model').train with the reference's batch format against the
+    reference fixture (Adam + cosine annealing, unroll 5, batch 128)."""
+    import torch
+    from muzero_amd.model import Muzero
+    fx = load_golden("train_lstmA_K5_B128.npz")
+    mz = Muzero(model_structure="lstm_model", observation_space_dimensions=4,
+                action_space_dimensions=2, state_space_dimensions=31, hidden_layer_dimensions=64,
+                number_of_hidden_layer=1, k_hypothetical_steps=5, learning_rate=0.01, optimizer="adam",
+                lr_scheduler="cosineannealinglr", num_of_epoch=10000)
+    mz.set_weights(fx["blob0"])
+    for s in range(2):
+        K, B, A = fx[f"s{s}_actions"].shape
+        batch = []
+        for b in range(B):
+            acts = [fx[f"s{s}_actions"][k, b] for k in range(K)]
+            tg = [[float(fx[f"s{s}_target_value"][k, b]), float(fx[f"s{s}_target_reward"][k, b]),
+                   fx[f"s{s}_target_policy"][k, b]] for k in range(K)]
+            batch.append((torch.tensor(fx[f"s{s}_obs"][b:b + 1]), acts, tg))
+        pos = np.stack([np.arange(B), np.arange(B)], axis=1)
+        prio, gp = mz.train((batch, fx[f"s{s}_is_ratio"], pos))
+        assert gp is pos and len(prio) == K and prio[0].shape == (B, 1)
+        L = fx[f"s{s}_losses"]
+        got = np.array([float(x) for x in mz.store_loss[-1]])
+        if s == 0:
+            assert np.all(np.abs(got - L) <= 1e-5 * np.abs(L) + 1e-7)
+        else:                      # second step starts from slightly different weights (Adam step 1)
+            assert np.all(np.abs(got - L) <= 5e-3 * np.abs(L) + 1e-4)
+        assert np.abs(mz.weights_blob() - fx[f"s{s}_blob"]).max() <= (s + 1) * 1e-2 * 0.01 + 1e-6
+    assert mz.count == 2
 
 
 def test_muzero_train_drop_in():

@@ -24,6 +24,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--lstm", action="store_true", help="also time the 'lstm_model' shape (config C4)")
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -44,9 +45,13 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
     torch.cuda.set_device(local)
 
-    w = np.load(os.path.join(ROOT, "tests", "golden", "weights_tag123.npz"))
-    dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L"))
-    for K, B in ((5, 128), (10, 128), (5, 1024)):
+    mlp = np.load(os.path.join(ROOT, "tests", "golden", "weights_tag123.npz"))
+    lstm = np.load(os.path.join(ROOT, "tests", "golden", "weights_lstmA.npz"))
+    cases = [(mlp, 0, 5, 128), (mlp, 0, 10, 128), (mlp, 0, 5, 1024)]
+    if args.lstm:     # BASELINE config C4 shape; every head's LSTM runs along the batch axis
+        cases += [(lstm, 1, 5, 128), (lstm, 1, 5, 512)]
+    for w, kind, K, B in cases:
+        dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (kind,)
         rs = np.random.RandomState(rank)
         eng = SearchEngine(dims, 1, 0, device=local)
         eng.set_weights(w["blob"])
@@ -84,7 +89,8 @@ def main():
             ar_us = 1e6 * shard.max_over_ranks(time.perf_counter() - t0, dev) / n
         shard.assert_replicas_identical(tr.weights(), dev)          # replicas stayed bit-identical
         if rank == 0:
-            print(json.dumps({"metric": "training step wall time", "unroll": K, "batch_per_gpu": B,
+            print(json.dumps({"metric": "training step wall time", "model": "lstm_model" if kind else "mlp_model",
+                              "unroll": K, "batch_per_gpu": B,
                               "n_gpus": world, "global_batch": B * world, "ms_per_step": 1e3 * dt,
                               "samples_per_s": B * world / dt, "allreduce_us": ar_us,
                               "bucket_floats": int(tr.grad.numel()),
