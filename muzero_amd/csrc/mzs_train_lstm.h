@@ -16,11 +16,14 @@
  *   - the 3K-1 head calls that do not feed the next hidden state (policy_k, value_k, reward_k):
  *     one workgroup each, forward + losses + backward in one launch (k_lstm_heads);
  *   - inside a call everything but the recurrence itself (the Linear, W_ih x_t for all t, and
- *     their transposes in the backward pass): all 16 waves of the workgroup;
+ *     their transposes in the backward pass): mini-GEMMs of the whole workgroup, rows staged
+ *     through LDS, 8 rows x 1 column per lane (lstm_block_gemm);
  * and what is serial is the next-state chain st_0 -> st_1 -> ... (one workgroup walks it forward,
  * k_lstm_chain_fwd, and backward, k_lstm_chain_bwd) and, inside every call, the B-step
- * recurrence: one wave, lane = LSTM unit, W_hh packed in LDS so that a step is n/4 x (one
- * 128-bit weight read + one broadcast read of h + 4 FMAs) per lane.
+ * recurrence.  Waves 0..3 of the workgroup are the four gates there: wave q keeps its gate's rows
+ * of W_hh in registers (lane = unit), so a step is 32 FMAs per lane, the gate activation, and ONE
+ * LDS-only barrier to swap gates (forward) or partial W_hh^T dz sums (backward) through LDS; rows
+ * are prefetched a register chunk ahead so that no global-memory wait sits inside a step.
  * Weight gradients are a separate, embarrassingly parallel pass over the stored deltas
  * (k_lstm_wgrad_partial / k_lstm_wgrad), fixed summation order, no atomics.
  */
@@ -31,7 +34,7 @@
 
 namespace mzs {
 
-constexpr int kLstmTrainThreads = 1024;
+constexpr int kLstmTrainThreads = 1024; /* 16 waves for the mini-GEMMs; waves 0..3 = the four gates of the recurrence */
 enum { kHeadRew = 0, kHeadSt = 1, kHeadPol = 2, kHeadVal = 3 };
 
 struct LstmTrainHead {
@@ -42,6 +45,7 @@ struct LstmTrainHead {
     long long wt_lin, wt_ih[kLstmMaxLayers]; /* tape offsets of W_lin^T [in][H], W_ih^T [in_l][4n] */
     /* field offsets inside one call's block (rows of max_batch capacity) */
     int u, du, dx, dout;
+    int ca[kLstmMaxLayers]; /* [B][n] backward coefficient o (1 - tanh^2 c) of the layer's rows */
     int gates[kLstmMaxLayers], c[kLstmMaxLayers], h[kLstmMaxLayers], dz[kLstmMaxLayers], dmid[kLstmMaxLayers];
 };
 
@@ -96,105 +100,305 @@ __device__ __forceinline__ float lt_tanh(float x) {
     return copysignf((1.0f - e) * __builtin_amdgcn_rcpf(1.0f + e), x);
 }
 
-/* LDS of the recurrence: packed W_hh (n_k4 * n float4), then h (64) and dz (256) rows */
-__host__ __device__ inline int lstm_train_lds_floats(int n_max) {
-    const int nk = (n_max + 3) / 4 * 4;
-    return 4 * nk * n_max + 64 + 256;
+/* The barrier inside the recurrence loops: what is exchanged is in LDS, so wait for LDS only.
+ * (__syncthreads() is also a workgroup-scope fence on global memory: it would drain the step's
+ * global stores and the prefetch of the next row, a full memory round trip per step.) */
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+/* LDS of one workgroup: the row tile of the mini-GEMMs, then the exchange buffers of the recurrence */
+constexpr int kLstmGemmLdsFloats = 12288;
+constexpr int kLstmRecurLdsFloats = 1024;
+constexpr int kLstmTrainLdsBytes = (kLstmGemmLdsFloats + kLstmRecurLdsFloats) * 4;
+constexpr int kLstmGemmRows = 8; /* rows per lane in the mini-GEMM */
+
+/* rows of a mini-GEMM's left operand */
+struct LstmRows {
+    const float* a;
+    int lda;
+    __device__ __forceinline__ const float* ptr(int t, int k) const { return a + (size_t)t * lda + k; }
+};
+
+/* C[t][j] = bias0[j] + bias1[j] + sum_k X[t][k] * Wt[k * ldw + j]   (t < B, j < N, k < Kd)
+ * X rows are staged through LDS a tile at a time; a lane owns column j of 8 rows, so one weight
+ * (coalesced over j) feeds 8 FMAs and the X operands are 128-bit broadcast reads.  Called by the whole
+ * workgroup; every thread must have finished writing X before the call returns from its first barrier. */
+__device__ void lstm_block_gemm(const LstmRows X, int B, int Kd, const float* __restrict__ Wt, int ldw, int N,
+                                const float* __restrict__ bias0, const float* __restrict__ bias1, float* C, int ldc,
+                                float* xl) {
+    const int tid = threadIdx.x, nt = blockDim.x, lane = tid & (kWave - 1), wave = tid / kWave, n_waves = nt / kWave;
+    const int Kp = (Kd + 3) & ~3;
+    int RB = (kLstmGemmLdsFloats / Kp) & ~(kLstmGemmRows - 1);
+    RB = RB > 128 ? 128 : RB;
+    const int ncg = (N + kWave - 1) / kWave;
+    for (int r0 = 0; r0 < B; r0 += RB) {
+        const int rows = B - r0 < RB ? B - r0 : RB;
+        __syncthreads(); /* X is complete; the previous tile has been consumed */
+        for (int base = tid; base < RB * Kp; base += 4 * nt) { /* four loads in flight per lane */
+            float v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = base + i * nt, r = idx / Kp, k = idx - r * Kp;
+                const bool ok = r < rows && k < Kd; /* rows past the tile's end also fail r < rows */
+                const float x = *X.ptr(ok ? r0 + r : r0, ok ? k : 0);
+                v[i] = ok ? x : 0.0f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (base + i * nt < RB * Kp) xl[base + i * nt] = v[i];
+        }
+        __syncthreads();
+        const int n_task = ncg * ((rows + kLstmGemmRows - 1) / kLstmGemmRows);
+        for (int task = wave; task < n_task; task += n_waves) {
+            const int cg = task % ncg, rt = task / ncg;
+            const int j = cg * kWave + lane, jj = j < N ? j : N - 1;
+            const float b = (bias0 ? bias0[jj] : 0.0f) + (bias1 ? bias1[jj] : 0.0f);
+            float acc[kLstmGemmRows];
+#pragma unroll
+            for (int i = 0; i < kLstmGemmRows; ++i) acc[i] = b;
+            const float* xr = xl + (size_t)rt * kLstmGemmRows * Kp;
+            const float* __restrict__ wc = Wt + jj;
+#pragma unroll 2
+            for (int k = 0; k < Kp; k += 4) {
+                /* rows past Kd meet zero X columns: any finite weight will do, stay inside the tensor */
+                const int k1 = k + 1 < Kd ? k + 1 : Kd - 1, k2 = k + 2 < Kd ? k + 2 : Kd - 1,
+                          k3 = k + 3 < Kd ? k + 3 : Kd - 1;
+                const float w0 = wc[(size_t)k * ldw], w1 = wc[(size_t)k1 * ldw], w2 = wc[(size_t)k2 * ldw],
+                            w3 = wc[(size_t)k3 * ldw];
+#pragma unroll
+                for (int i = 0; i < kLstmGemmRows; ++i) {
+                    const float4 x = *reinterpret_cast<const float4*>(xr + (size_t)i * Kp + k);
+                    acc[i] = fmaf(w0, x.x, acc[i]);
+                    acc[i] = fmaf(w1, x.y, acc[i]);
+                    acc[i] = fmaf(w2, x.z, acc[i]);
+                    acc[i] = fmaf(w3, x.w, acc[i]);
+                }
+            }
+            if (j < N)
+#pragma unroll
+                for (int i = 0; i < kLstmGemmRows; ++i) {
+                    const int r = rt * kLstmGemmRows + i;
+                    if (r < rows) C[(size_t)(r0 + r) * ldc + j] = acc[i];
+                }
+        }
+    }
+    __syncthreads();
+}
+
+/* The forward recurrence of one layer along the batch axis.  Waves 0..3 = gates i, f, g, o (torch
+ * row order), lane = unit; the wave's W_hh rows sit in NK registers per lane.  g [B][4n] holds the
+ * input half of the pre-activations on entry and the activated gates on return.  One LDS-only
+ * barrier per step: the gates are exchanged through a double-buffered LDS row, h is kept in a
+ * private LDS row per wave.  The input halves arrive in register chunks of 8 rows, loaded one chunk
+ * ahead, and every store is unconditional (lanes past n repeat lane n-1 and all four waves hold the
+ * same c and h: identical values to identical addresses), so the step is straight-line code and no
+ * global-memory wait sits inside it.  Waves 4.. only keep the barrier count. */
+template <int NK>
+__device__ __noinline__ void lstm_recur_fwd(const float* __restrict__ Whh, int n, int B, float* g, float* cb, float* hb,
+                               float* ls) {
+    const int q = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1), j = lane < n ? lane : n - 1;
+    if (q >= 4) {
+        for (int t = 0; t < B; ++t) lds_barrier();
+        __syncthreads();
+        return;
+    }
+    const bool act = lane < n;
+    const int n4 = 4 * n;
+    float w[NK];
+#pragma unroll
+    for (int k = 0; k < NK; ++k) w[k] = k < n ? Whh[(size_t)(q * n + j) * n + k] : 0.0f;
+    float* hbuf = ls + q * kWave;  /* [4][64] */
+    float* gact = ls + 4 * kWave;  /* [2][4][64] */
+    hbuf[lane] = 0.0f;
+    wave_sync();
+    /* tanh(x) = 2 sigmoid(2x) - 1: one branch-free activation for all four gates */
+    const float a_in = q == 2 ? 2.0f : 1.0f, a_mul = q == 2 ? 2.0f : 1.0f, a_add = q == 2 ? -1.0f : 0.0f;
+    float cprev = 0.0f;
+    float* gq = g + q * n + j; /* this lane's gate entry of row t: gq[t * n4] */
+    const auto step = [&](int t, float z) {
+        float z0 = z, z1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NK; k += 4) {
+            const float4 hv = *reinterpret_cast<const float4*>(hbuf + k);
+            z0 = fmaf(w[k], hv.x, z0);
+            z1 = fmaf(w[k + 1], hv.y, z1);
+            z0 = fmaf(w[k + 2], hv.z, z0);
+            z1 = fmaf(w[k + 3], hv.w, z1);
+        }
+        const float a = fmaf(lt_sigmoid(a_in * (z0 + z1)), a_mul, a_add);
+        float* ga = gact + (t & 1) * 4 * kWave;
+        ga[q * kWave + lane] = a;
+        gq[(size_t)t * n4] = a;
+        lds_barrier();
+        const float ig = ga[lane], fg = ga[kWave + lane], gg = ga[2 * kWave + lane], og = ga[3 * kWave + lane];
+        const float cv = fg * cprev + ig * gg;
+        const float hv = og * lt_tanh(cv);
+        hbuf[lane] = act ? hv : 0.0f;
+        cb[(size_t)t * n + j] = cv;
+        hb[(size_t)t * n + j] = hv;
+        wave_sync();
+        cprev = cv;
+    };
+    constexpr int CH = 8;
+    float zc[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) zc[i] = gq[(size_t)(i < B ? i : B - 1) * n4];
+    int t0 = 0;
+    for (; t0 + CH <= B; t0 += CH) {
+        float zn[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            const int tn = t0 + CH + i;
+            zn[i] = gq[(size_t)(tn < B ? tn : B - 1) * n4];
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) step(t0 + i, zc[i]);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) zc[i] = zn[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+        if (t0 + i < B) step(t0 + i, zc[i]);
+    __syncthreads();
+}
+
+/* Everything of the backward cell step that does not depend on the incoming gradient, for every row
+ * at once: A = o (1 - tanh^2 c) to ca, and the four factors P_q that turn dL/dc (dL/dh for the output
+ * gate) into the pre-activation gradient of gate q, written where dz will go. */
+__device__ void lstm_bwd_coefficients(int n, int B, const float* g, const float* cb, float* ca, float* dz) {
+    const int n4 = 4 * n;
+    for (int idx = threadIdx.x; idx < B * n; idx += blockDim.x) {
+        const int t = idx / n, j = idx - t * n;
+        const float* gt = g + (size_t)t * n4;
+        const float ig = gt[j], fg = gt[n + j], gg = gt[2 * n + j], og = gt[3 * n + j];
+        const float cp = t > 0 ? cb[idx - n] : 0.0f;
+        const float tc = lt_tanh(cb[idx]);
+        ca[idx] = og * (1.0f - tc * tc);
+        float* d = dz + (size_t)t * n4;
+        d[j] = gg * ig * (1.0f - ig);
+        d[n + j] = cp * fg * (1.0f - fg);
+        d[2 * n + j] = ig * (1.0f - gg * gg);
+        d[3 * n + j] = tc * og * (1.0f - og);
+    }
+    __syncthreads();
+}
+
+/* The backward recurrence of one layer (after lstm_bwd_coefficients).  Every wave 0..3 carries
+ * dL/dc along (dc = dh A + dc_next f), turns it into the pre-activation gradient of ITS gate
+ * (d = P_q dc, P_o dh for the output gate) and sums its gate's share of W_hh^T dz (lane = unit of
+ * h_{t-1}, the wave's W_hh rows in registers, column `lane`); the four shares meet through a
+ * double-buffered LDS row: one LDS-only barrier per step.  Rows arrive in register chunks of 4, one
+ * chunk ahead; stores are unconditional as in the forward loop. */
+template <int NK>
+__device__ __noinline__ void lstm_recur_bwd(const float* __restrict__ Whh, int n, int B, const float* g, const float* ca,
+                               const float* dO, float* dz, float* ls) {
+    const int q = threadIdx.x / kWave, lane = threadIdx.x & (kWave - 1), j = lane < n ? lane : n - 1;
+    if (q >= 4) {
+        for (int t = 0; t < B; ++t) lds_barrier();
+        __syncthreads();
+        return;
+    }
+    const bool act = lane < n;
+    const int n4 = 4 * n;
+    float w[NK];
+#pragma unroll
+    for (int r = 0; r < NK; ++r) w[r] = r < n ? Whh[(size_t)(q * n + r) * n + j] : 0.0f;
+    float* dzb = ls + q * kWave;   /* [4][64]: this wave's dz row */
+    float* part = ls + 4 * kWave;  /* [2][4][64] */
+    dzb[lane] = 0.0f;
+    float dcn = 0.0f, dhr = 0.0f;
+    const float* fq = g + n + j;        /* forget gate of row t: fq[t * n4] */
+    float* dq = dz + q * n + j;         /* P_q on entry, dz on return: dq[t * n4] */
+    const float* dOj = dO + j;
+    const float* caj = ca + j;
+    struct Row {
+        float dov, a, f, p;
+    };
+    const auto load = [&](int t) {
+        const int tt = t > 0 ? t : 0;
+        Row r;
+        r.dov = dOj[(size_t)tt * n], r.a = caj[(size_t)tt * n], r.f = fq[(size_t)tt * n4], r.p = dq[(size_t)tt * n4];
+        return r;
+    };
+    const auto step = [&](int t, const Row r) {
+        const float dh = r.dov + dhr;
+        const float dc = dh * r.a + dcn;
+        dcn = dc * r.f;
+        const float d = (q == 3 ? dh : dc) * r.p;
+        dq[(size_t)t * n4] = d;
+        dzb[lane] = act ? d : 0.0f;
+        wave_sync();
+        float a0 = 0.0f, a1 = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NK; k += 4) {
+            const float4 e = *reinterpret_cast<const float4*>(dzb + k);
+            a0 = fmaf(w[k], e.x, a0);
+            a1 = fmaf(w[k + 1], e.y, a1);
+            a0 = fmaf(w[k + 2], e.z, a0);
+            a1 = fmaf(w[k + 3], e.w, a1);
+        }
+        float* pp = part + (t & 1) * 4 * kWave;
+        pp[q * kWave + lane] = a0 + a1;
+        lds_barrier();
+        dhr = (pp[lane] + pp[kWave + lane]) + (pp[2 * kWave + lane] + pp[3 * kWave + lane]);
+    };
+    constexpr int CH = 4;
+    Row rc[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) rc[i] = load(B - 1 - i);
+    int t1 = B; /* rows [0, t1) are still to do; rc[i] = row t1 - 1 - i */
+    for (; t1 >= CH; t1 -= CH) {
+        Row rn[CH];
+#pragma unroll
+        for (int i = 0; i < CH; ++i) rn[i] = load(t1 - CH - 1 - i);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) step(t1 - 1 - i, rc[i]);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) rc[i] = rn[i];
+    }
+#pragma unroll
+    for (int i = 0; i < CH; ++i)
+        if (t1 - 1 - i >= 0) step(t1 - 1 - i, rc[i]);
+    __syncthreads();
 }
 
 /* Forward of call k of head hd: rows x_t = (h_k[t], action_k[t]) -> u, gates, c, h on the tape. */
 __device__ void lstm_head_fwd(const LstmTrainParams& p, int hd, int k, float* lds) {
     const LstmTrainHead& hh = p.head[hd];
     const int B = p.B, H = p.H, n = hh.n, Sd = p.Sd, A = p.A, L = p.L;
-    const int tid = threadIdx.x, nt = blockDim.x, n4 = 4 * n, nk = (n + 3) / 4 * 4;
-    const float* xh = lt_hstate(p, k);
-    const float* __restrict__ xa = hd < 2 ? p.actions + (size_t)k * B * A : nullptr;
+    float* xl = lds;
+    float* ls = lds + kLstmGemmLdsFloats;
     float* u = lt_field(p, hd, k, hh.u);
     {
+        const LstmRows X{lt_hstate(p, k), Sd};
         const float* __restrict__ WT = p.tape + hh.wt_lin;
-        for (int idx = tid; idx < B * H; idx += nt) {
-            const int t = idx / H, j = idx - t * H;
-            float acc = p.blob[hh.lin_b + j];
-            for (int kk = 0; kk < Sd; ++kk) acc = fmaf(WT[kk * H + j], xh[(size_t)t * Sd + kk], acc);
-            if (xa)
-                for (int a = 0; a < A; ++a) acc = fmaf(WT[(Sd + a) * H + j], xa[(size_t)t * A + a], acc);
-            u[idx] = acc;
+        lstm_block_gemm(X, B, Sd, WT, H, H, p.blob + hh.lin_b, nullptr, u, H, xl);
+        if (hd < 2) { /* the action columns of the dynamics input (one-hot, or zero for absorbing rows) */
+            const float* __restrict__ xa = p.actions + (size_t)k * B * A;
+            for (int idx = threadIdx.x; idx < B * H; idx += blockDim.x) {
+                const int t = idx / H, j = idx - t * H;
+                float acc = u[idx];
+                for (int a = 0; a < A; ++a) acc = fmaf(WT[(size_t)(Sd + a) * H + j], xa[(size_t)t * A + a], acc);
+                u[idx] = acc;
+            }
         }
     }
-    float4* W4 = reinterpret_cast<float4*>(lds);
-    float* hbuf = lds + 4 * nk * n;
     for (int l = 0; l < L; ++l) {
         const int in_l = l == 0 ? H : n;
-        /* W_hh -> LDS as [k][unit] float4 (i, f, g, o rows of that unit), zero rows up to nk */
-        const float* __restrict__ Whh = p.blob + hh.w_hh[l];
-        for (int idx = tid; idx < nk * n; idx += nt) {
-            const int kk = idx / n, j = idx - kk * n;
-            float4 w = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-            if (kk < n) {
-                w.x = Whh[(size_t)j * n + kk];
-                w.y = Whh[(size_t)(n + j) * n + kk];
-                w.z = Whh[(size_t)(2 * n + j) * n + kk];
-                w.w = Whh[(size_t)(3 * n + j) * n + kk];
-            }
-            W4[idx] = w;
-        }
-        __syncthreads(); /* u (or the layer below) is complete */
-        const float* xs = l == 0 ? u : lt_layer_h(p, hd, k, l - 1);
-        const float* __restrict__ WT = p.tape + hh.wt_ih[l];
         float* g = lt_field(p, hd, k, hh.gates[l]);
-        const float* __restrict__ bi = p.blob + hh.b_ih[l];
-        const float* __restrict__ bh = p.blob + hh.b_hh[l];
         /* input half of the gate pre-activations for every row at once */
-        for (int idx = tid; idx < B * n4; idx += nt) {
-            const int t = idx / n4, jj = idx - t * n4;
-            float acc = bi[jj] + bh[jj];
-            const float* x = xs + (size_t)t * in_l;
-            for (int kk = 0; kk < in_l; ++kk) acc = fmaf(WT[kk * n4 + jj], x[kk], acc);
-            g[idx] = acc;
-        }
-        __syncthreads();
-        /* the recurrence along the batch axis: wave 0, lane = unit */
-        if (tid < kWave) {
-            const int lane = tid, j = lane < n ? lane : 0;
-            const bool act = lane < n;
-            float* cb = lt_field(p, hd, k, hh.c[l]);
-            float* hb = lt_layer_h(p, hd, k, l);
-            hbuf[lane] = 0.0f;
-            wave_sync();
-            float cprev = 0.0f;
-            float z0 = g[j], z1 = g[n + j], z2 = g[2 * n + j], z3 = g[3 * n + j];
-            for (int t = 0; t < B; ++t) {
-                float y0 = 0.0f, y1 = 0.0f, y2 = 0.0f, y3 = 0.0f;
-                if (t + 1 < B) { /* next row's input half: in flight during this step */
-                    const float* gn = g + (size_t)(t + 1) * n4;
-                    y0 = gn[j], y1 = gn[n + j], y2 = gn[2 * n + j], y3 = gn[3 * n + j];
-                }
-                for (int kk = 0; kk < nk; kk += 4) {
-                    const float4 hv = *reinterpret_cast<const float4*>(hbuf + kk);
-                    const float4 w0 = W4[kk * n + j], w1 = W4[(kk + 1) * n + j], w2 = W4[(kk + 2) * n + j],
-                                 w3 = W4[(kk + 3) * n + j];
-                    z0 = fmaf(w0.x, hv.x, z0), z1 = fmaf(w0.y, hv.x, z1), z2 = fmaf(w0.z, hv.x, z2), z3 = fmaf(w0.w, hv.x, z3);
-                    z0 = fmaf(w1.x, hv.y, z0), z1 = fmaf(w1.y, hv.y, z1), z2 = fmaf(w1.z, hv.y, z2), z3 = fmaf(w1.w, hv.y, z3);
-                    z0 = fmaf(w2.x, hv.z, z0), z1 = fmaf(w2.y, hv.z, z1), z2 = fmaf(w2.z, hv.z, z2), z3 = fmaf(w2.w, hv.z, z3);
-                    z0 = fmaf(w3.x, hv.w, z0), z1 = fmaf(w3.y, hv.w, z1), z2 = fmaf(w3.z, hv.w, z2), z3 = fmaf(w3.w, hv.w, z3);
-                }
-                const float ig = lt_sigmoid(z0), fg = lt_sigmoid(z1), gg = lt_tanh(z2), og = lt_sigmoid(z3);
-                const float cv = fg * cprev + ig * gg;
-                const float hv = og * lt_tanh(cv);
-                wave_sync(); /* every lane has read the old h */
-                if (act) {
-                    float* gt = g + (size_t)t * n4;
-                    gt[j] = ig, gt[n + j] = fg, gt[2 * n + j] = gg, gt[3 * n + j] = og;
-                    cb[(size_t)t * n + j] = cv;
-                    hb[(size_t)t * n + j] = hv;
-                    hbuf[lane] = hv;
-                }
-                wave_sync();
-                cprev = cv;
-                z0 = y0, z1 = y1, z2 = y2, z3 = y3;
-            }
-        }
-        __syncthreads();
+        const LstmRows X{l == 0 ? u : lt_layer_h(p, hd, k, l - 1), in_l};
+        lstm_block_gemm(X, B, in_l, p.tape + hh.wt_ih[l], 4 * n, 4 * n, p.blob + hh.b_ih[l], p.blob + hh.b_hh[l], g,
+                        4 * n, xl);
+        float* cb = lt_field(p, hd, k, hh.c[l]);
+        float* hb = lt_layer_h(p, hd, k, l);
+        if (n <= 32)
+            lstm_recur_fwd<32>(p.blob + hh.w_hh[l], n, B, g, cb, hb, ls);
+        else
+            lstm_recur_fwd<64>(p.blob + hh.w_hh[l], n, B, g, cb, hb, ls);
     }
 }
 
@@ -202,111 +406,31 @@ __device__ void lstm_head_fwd(const LstmTrainParams& p, int hd, int k, float* ld
  * layer, du, and dx [B][Sd] = dL/d(h_k rows) through this call. */
 __device__ void lstm_head_bwd(const LstmTrainParams& p, int hd, int k, const float* dOut, float* lds) {
     const LstmTrainHead& hh = p.head[hd];
-    const int B = p.B, H = p.H, n = hh.n, Sd = p.Sd, L = p.L, in = hh.in_dim;
-    const int tid = threadIdx.x, nt = blockDim.x, n4 = 4 * n;
-    float4* Wb = reinterpret_cast<float4*>(lds);
-    float* dzb = lds + 4 * ((n + 3) / 4 * 4) * n + 64;
+    const int B = p.B, H = p.H, n = hh.n, Sd = p.Sd, L = p.L;
+    float* xl = lds;
+    float* ls = lds + kLstmGemmLdsFloats;
     float* du = lt_field(p, hd, k, hh.du);
+    __syncthreads(); /* dOut is complete */
     for (int l = L - 1; l >= 0; --l) {
         const int in_l = l == 0 ? H : n;
-        /* W_hh -> LDS as [row group][unit] float4: rows 4g..4g+3 of column `unit` */
-        const float* __restrict__ Whh = p.blob + hh.w_hh[l];
-        for (int idx = tid; idx < n * n; idx += nt) {
-            const int gq = idx / n, kk = idx - gq * n;
-            Wb[idx] = make_float4(Whh[(size_t)(4 * gq) * n + kk], Whh[(size_t)(4 * gq + 1) * n + kk],
-                                  Whh[(size_t)(4 * gq + 2) * n + kk], Whh[(size_t)(4 * gq + 3) * n + kk]);
-        }
-        __syncthreads(); /* dOut of this layer is complete */
         const float* g = lt_field(p, hd, k, hh.gates[l]);
         const float* cb = lt_field(p, hd, k, hh.c[l]);
         float* dz = lt_field(p, hd, k, hh.dz[l]);
         const float* dO = l == L - 1 ? dOut : lt_field(p, hd, k, hh.dmid[l]);
-        if (tid < kWave) {
-            const int lane = tid, j = lane < n ? lane : 0;
-            const bool act = lane < n;
-            for (int i = lane; i < 256; i += kWave) dzb[i] = 0.0f;
-            wave_sync();
-            float dcn = 0.0f, dhr = 0.0f;
-            int t = B - 1;
-            const float* gt = g + (size_t)t * n4;
-            float ig = gt[j], fg = gt[n + j], gg = gt[2 * n + j], og = gt[3 * n + j];
-            float cv = cb[(size_t)t * n + j], cp = t > 0 ? cb[(size_t)(t - 1) * n + j] : 0.0f;
-            float dov = dO[(size_t)t * n + j];
-            for (; t >= 0; --t) {
-                float nig = 0.0f, nfg = 0.0f, ngg = 0.0f, nog = 0.0f, ncp = 0.0f, ndo = 0.0f;
-                if (t > 0) { /* the previous row's record: in flight during this step */
-                    const float* gp = g + (size_t)(t - 1) * n4;
-                    nig = gp[j], nfg = gp[n + j], ngg = gp[2 * n + j], nog = gp[3 * n + j];
-                    ncp = t > 1 ? cb[(size_t)(t - 2) * n + j] : 0.0f;
-                    ndo = dO[(size_t)(t - 1) * n + j];
-                }
-                const float dh = dov + dhr;
-                const float tc = lt_tanh(cv);
-                const float dc = dh * og * (1.0f - tc * tc) + dcn;
-                const float d0 = dc * gg * ig * (1.0f - ig);
-                const float d1 = dc * cp * fg * (1.0f - fg);
-                const float d2 = dc * ig * (1.0f - gg * gg);
-                const float d3 = dh * tc * og * (1.0f - og);
-                dcn = dc * fg;
-                if (act) {
-                    float* dzt = dz + (size_t)t * n4;
-                    dzt[j] = d0, dzt[n + j] = d1, dzt[2 * n + j] = d2, dzt[3 * n + j] = d3;
-                    dzb[j] = d0, dzb[n + j] = d1, dzb[2 * n + j] = d2, dzb[3 * n + j] = d3;
-                }
-                wave_sync();
-                /* dL/dh_{t-1} through W_hh: lane = unit of h_{t-1} */
-                float a0 = 0.0f, a1 = 0.0f;
-                for (int gq = 0; gq + 1 < n; gq += 2) {
-                    const float4 w0 = Wb[gq * n + j], w1 = Wb[(gq + 1) * n + j];
-                    const float4 e0 = *reinterpret_cast<const float4*>(dzb + 4 * gq);
-                    const float4 e1 = *reinterpret_cast<const float4*>(dzb + 4 * gq + 4);
-                    a0 = fmaf(w0.x, e0.x, a0), a0 = fmaf(w0.y, e0.y, a0), a0 = fmaf(w0.z, e0.z, a0), a0 = fmaf(w0.w, e0.w, a0);
-                    a1 = fmaf(w1.x, e1.x, a1), a1 = fmaf(w1.y, e1.y, a1), a1 = fmaf(w1.z, e1.z, a1), a1 = fmaf(w1.w, e1.w, a1);
-                }
-                if (n & 1) {
-                    const float4 w0 = Wb[(n - 1) * n + j];
-                    const float4 e0 = *reinterpret_cast<const float4*>(dzb + 4 * (n - 1));
-                    a0 = fmaf(w0.x, e0.x, a0), a0 = fmaf(w0.y, e0.y, a0), a0 = fmaf(w0.z, e0.z, a0), a0 = fmaf(w0.w, e0.w, a0);
-                }
-                dhr = a0 + a1;
-                wave_sync();
-                cv = cp; /* c_{t-1} */
-                ig = nig, fg = nfg, gg = ngg, og = nog, cp = ncp, dov = ndo;
-            }
-        }
-        __syncthreads();
-        /* dL/d(layer input rows) = W_ih^T dz, every row at once */
-        const float* __restrict__ Wih = p.blob + hh.w_ih[l];
-        float* dst = l == 0 ? du : lt_field(p, hd, k, hh.dmid[l - 1]);
-        for (int idx = tid; idx < B * in_l; idx += nt) {
-            const int t = idx / in_l, kk = idx - t * in_l;
-            const float* d = dz + (size_t)t * n4;
-            float a0 = 0.0f, a1 = 0.0f;
-            int jj = 0;
-            for (; jj + 1 < n4; jj += 2) {
-                a0 = fmaf(Wih[(size_t)jj * in_l + kk], d[jj], a0);
-                a1 = fmaf(Wih[(size_t)(jj + 1) * in_l + kk], d[jj + 1], a1);
-            }
-            dst[idx] = a0 + a1;
-        }
-        __syncthreads();
+        float* ca = lt_field(p, hd, k, hh.ca[l]);
+        lstm_bwd_coefficients(n, B, g, cb, ca, dz);
+        if (n <= 32)
+            lstm_recur_bwd<32>(p.blob + hh.w_hh[l], n, B, g, ca, dO, dz, ls);
+        else
+            lstm_recur_bwd<64>(p.blob + hh.w_hh[l], n, B, g, ca, dO, dz, ls);
+        /* dL/d(layer input rows) = dz W_ih, every row at once (W_ih [4n][in_l] is its own "transposed" form) */
+        const LstmRows X{dz, 4 * n};
+        lstm_block_gemm(X, B, 4 * n, p.blob + hh.w_ih[l], in_l, in_l, nullptr, nullptr,
+                        l == 0 ? du : lt_field(p, hd, k, hh.dmid[l - 1]), in_l, xl);
     }
     /* dL/dh_k rows through the Linear (the action columns get a gradient nobody uses) */
-    const float* __restrict__ Wl = p.blob + hh.lin_w;
-    float* dx = lt_field(p, hd, k, hh.dx);
-    for (int idx = tid; idx < B * Sd; idx += nt) {
-        const int t = idx / Sd, kk = idx - t * Sd;
-        const float* d = du + (size_t)t * H;
-        float a0 = 0.0f, a1 = 0.0f;
-        int j = 0;
-        for (; j + 1 < H; j += 2) {
-            a0 = fmaf(Wl[(size_t)j * in + kk], d[j], a0);
-            a1 = fmaf(Wl[(size_t)(j + 1) * in + kk], d[j + 1], a1);
-        }
-        if (j < H) a0 = fmaf(Wl[(size_t)j * in + kk], d[j], a0);
-        dx[idx] = a0 + a1;
-    }
-    __syncthreads();
+    const LstmRows X{du, H};
+    lstm_block_gemm(X, B, H, p.blob + hh.lin_w, hh.in_dim, Sd, nullptr, nullptr, lt_field(p, hd, k, hh.dx), Sd, xl);
 }
 
 /* transposed copies of the forward weights (coalesced over the output neuron): blockIdx.y = head */

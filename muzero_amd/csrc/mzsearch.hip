@@ -1561,7 +1561,7 @@ static LstmTrainPlan make_lstm_train_plan(const mzs_dims& d, int K, int Bcap) {
             t.b_ih[l] = (int)o.b_ih[l], t.b_hh[l] = (int)o.b_hh[l];
             t.wt_ih[l] = take((long long)(l == 0 ? H : n) * 4 * n);
             t.gates[l] = field(4 * n), t.c[l] = field(n), t.h[l] = field(n), t.dz[l] = field(4 * n),
-            t.dmid[l] = field(n);
+            t.dmid[l] = field(n), t.ca[l] = field(n);
         }
         t.stride = r;
         const int n_calls = hd < 2 ? (K > 1 ? K - 1 : 0) : K;
@@ -1622,9 +1622,6 @@ static LstmTrainPlan make_lstm_train_plan(const mzs_dims& d, int K, int Bcap) {
 
 static int lstm_train_create(mzs_handle* h, int32_t max_batch, int32_t unroll_steps) {
     const mzs_dims& d = h->cfg.dims;
-    const int n_max = d.state_dim > d.n_actions ? d.state_dim : d.n_actions;
-    if ((size_t)lstm_train_lds_floats(n_max) * sizeof(float) > (size_t)kMaxLdsPerBlock)
-        return fail(MZS_E_ARG, "lstm_model training: packed W_hh does not fit 160 KiB of LDS");
     LstmTrainPlan pl = make_lstm_train_plan(d, unroll_steps, max_batch);
     for (size_t i = 0; i < pl.param_desc.size(); ++i)
         if (pl.param_desc[i] < 0) return fail(MZS_E_STATE, "lstm_model training: a parameter has no gradient descriptor");
@@ -1664,16 +1661,7 @@ static int lstm_train_grad_launch(mzs_handle* h, int32_t batch, const float* obs
     p.tp = target_policy_dev, p.is_ratio = is_ratio_dev;
     p.priority = priority_dev, p.grad = grad_dev, p.loss_out = loss_dev;
     const int K = p.K;
-    const int n_max = p.Sd > p.A ? p.Sd : p.A;
-    const size_t shmem = (size_t)lstm_train_lds_floats(n_max) * sizeof(float);
-    if (shmem > 64 * 1024) {
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_chain_fwd),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_heads),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lstm_chain_bwd),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
-    }
+    const size_t shmem = kLstmTrainLdsBytes; /* under 64 KiB: no attribute to raise */
     hipLaunchKernelGGL(k_lstm_prep, dim3(8, 4), dim3(256), 0, st, p);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(k_lstm_chain_fwd, dim3(1), dim3(kLstmTrainThreads), shmem, st, p);
