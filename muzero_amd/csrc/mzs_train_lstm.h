@@ -109,6 +109,14 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
+/* Tape pointers inside the (non-inlined) recurrence functions, tagged as global memory: through a
+ * generic pointer every access would be a FLAT operation, which also counts as an LDS operation,
+ * and the LDS-only wait before each barrier would then wait for global memory after all. */
+typedef __attribute__((address_space(1))) float gfloat;
+typedef __attribute__((address_space(1))) const float gcfloat;
+__device__ __forceinline__ gfloat* as_global(float* p) { return (gfloat*)p; }
+__device__ __forceinline__ gcfloat* as_global(const float* p) { return (gcfloat*)p; }
+
 /* LDS of one workgroup: the row tile of the mini-GEMMs, then the exchange buffers of the recurrence */
 constexpr int kLstmGemmLdsFloats = 12288;
 constexpr int kLstmRecurLdsFloats = 1024;
@@ -217,7 +225,9 @@ __device__ __noinline__ void lstm_recur_fwd(const float* __restrict__ Whh, int n
     /* tanh(x) = 2 sigmoid(2x) - 1: one branch-free activation for all four gates */
     const float a_in = q == 2 ? 2.0f : 1.0f, a_mul = q == 2 ? 2.0f : 1.0f, a_add = q == 2 ? -1.0f : 0.0f;
     float cprev = 0.0f;
-    float* gq = g + q * n + j; /* this lane's gate entry of row t: gq[t * n4] */
+    gfloat* gq = as_global(g + q * n + j); /* this lane's gate entry of row t: gq[t * n4] */
+    gfloat* cbj = as_global(cb + j);
+    gfloat* hbj = as_global(hb + j);
     const auto step = [&](int t, float z) {
         float z0 = z, z1 = 0.0f;
 #pragma unroll
@@ -237,8 +247,8 @@ __device__ __noinline__ void lstm_recur_fwd(const float* __restrict__ Whh, int n
         const float cv = fg * cprev + ig * gg;
         const float hv = og * lt_tanh(cv);
         hbuf[lane] = act ? hv : 0.0f;
-        cb[(size_t)t * n + j] = cv;
-        hb[(size_t)t * n + j] = hv;
+        cbj[(size_t)t * n] = cv;
+        hbj[(size_t)t * n] = hv;
         wave_sync();
         cprev = cv;
     };
@@ -310,10 +320,10 @@ __device__ __noinline__ void lstm_recur_bwd(const float* __restrict__ Whh, int n
     float* part = ls + 4 * kWave;  /* [2][4][64] */
     dzb[lane] = 0.0f;
     float dcn = 0.0f, dhr = 0.0f;
-    const float* fq = g + n + j;        /* forget gate of row t: fq[t * n4] */
-    float* dq = dz + q * n + j;         /* P_q on entry, dz on return: dq[t * n4] */
-    const float* dOj = dO + j;
-    const float* caj = ca + j;
+    gcfloat* fq = as_global(g + n + j);   /* forget gate of row t: fq[t * n4] */
+    gfloat* dq = as_global(dz + q * n + j); /* P_q on entry, dz on return: dq[t * n4] */
+    gcfloat* dOj = as_global(dO + j);
+    gcfloat* caj = as_global(ca + j);
     struct Row {
         float dov, a, f, p;
     };
@@ -527,7 +537,7 @@ __global__ void __launch_bounds__(kLstmTrainThreads) k_lstm_chain_bwd(const Lstm
     }
 }
 
-constexpr int kLstmWgradRows = 16; /* batch rows per partial sum */
+constexpr int kLstmWgradRows = 8; /* batch rows per partial sum */
 
 /* pass 1: thread (blob element, row chunk) = sum over the chunk's rows and over the tensor's calls
  * of delta * input -> partial[chunk][element] */
@@ -545,6 +555,7 @@ __global__ void __launch_bounds__(256) k_lstm_wgrad_partial(const LstmTrainParam
     for (int call = 0; call < d.n_calls; ++call) {
         const float* dl = p.tape + d.d_base + call * d.d_stride + r;
         const float* x = xsrc + d.x_base + call * xs + c;
+#pragma unroll 4
         for (int t = max(b0, d.t_shift); t < b1; ++t) {
             const float xv = d.n_cols ? x[(size_t)(t - d.t_shift) * d.x_ld] : 1.0f;
             acc += (double)dl[(size_t)t * d.d_ld] * (double)xv;
@@ -572,8 +583,15 @@ __global__ void __launch_bounds__(256) k_lstm_wgrad(const LstmTrainParams p, con
     }
     __shared__ double red[256];
     double sq = 0.0;
-    for (int i = threadIdx.x; i < p.n_params; i += blockDim.x)
-        if (p.desc[p.param_desc[i]].l2) sq += (double)p.blob[i] * p.blob[i];
+    for (int di = 0; di < p.n_desc; ++di) { /* the few tensors of the l2 term, one after the other */
+        const LstmGradDesc& d = p.desc[di];
+        if (!d.l2) continue;
+        const int nc = d.n_cols ? d.n_cols : 1;
+        for (int e = threadIdx.x; e < d.n_rows * nc; e += blockDim.x) {
+            const float wv = p.blob[d.w_off + (e / nc) * d.ld + e % nc];
+            sq += (double)wv * wv;
+        }
+    }
     double tot = 0.0, wsum = 0.0;
     for (int b = threadIdx.x; b < B; b += blockDim.x) {
         const double wb = (double)((p.is_ratio ? p.is_ratio[b] : 1.0f) * p.inv_batch);
