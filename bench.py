@@ -183,10 +183,9 @@ def main():
     value = sims_per_step * args.steps / elapsed
 
     # the same step with its random streams generated on the device first (a self-play move needs
-    # fresh streams: mzs_fill_streams + mzs_search), timed separately: never part of `value`
+    # fresh streams: mzs_search_streams), timed separately: never part of `value`
     def step_streams():
-        d_, n_ = eng.fill_streams(seeds_d, S, True)
-        eng.search(obs_d, d_, n_, S, True)
+        eng.search_streams(obs_d, seeds_d, S, True)
 
     for _ in range(min(args.warmup, 3)):
         step_streams()

@@ -94,6 +94,22 @@ int mzs_fill_streams(mzs_handle* h, int32_t n_games, int32_t num_simulations, in
                      const int64_t* seeds_dev, double alpha, double lo, double hi,
                      double* dirichlet_dev, double* noise_dev, int64_t noise_stride, void* stream);
 
+/* mzs_fill_streams + mzs_search as the self-play loop needs them once per move, without writing
+ * the whole worst-case stream first: a search of S simulations may read up to mzs_max_draws(A, S)
+ * tie-break draws (one chain of S nodes) but typically reads a fifth of that.  This call
+ *   1. writes the Dirichlet rows and the first prefix_draws uniform draws of every game
+ *      (prefix_draws <= 0: 9 * A * S, about twice the typical consumption),
+ *   2. searches; a game whose search wants a draw past the prefix is flagged (mzs_results status),
+ *   3. for the flagged games only: writes the whole stream and searches again.
+ * Steps 1-2 are the common case; the two launches of step 3 leave at once when no game is flagged.
+ * Results (mzs_results, tree arrays) equal those of mzs_fill_streams + mzs_search bit for bit;
+ * dirichlet_dev [n_games][A] and noise_dev [n_games][noise_stride >= mzs_max_draws] are the
+ * caller's scratch.  Reference: the same np.random draws, monte_carlo_tree_search.py:140, :163. */
+int mzs_search_streams(mzs_handle* h, int32_t n_games, int32_t num_simulations, int32_t train,
+                       const float* obs_dev, const int64_t* seeds_dev, double alpha, double lo, double hi,
+                       int32_t prefix_draws, double* dirichlet_dev, double* noise_dev, int64_t noise_stride,
+                       void* stream);
+
 /* Same search with the model outputs supplied instead of computed (L1 parity mode): isolates
  * ucb_score/select_child/expand/backup (mcts.py:155-209) from the network arithmetic.
  *   root_policy_dev [n_games][A], sim_reward_dev/sim_value_dev [n_games][S],
@@ -275,6 +291,16 @@ int mzs_arena_enqueue(mzs_arena* arena, int32_t n_games, const int64_t* seeds_de
 int mzs_arena_step(mzs_arena* arena, const int32_t* visits_dev, const float* root_value_dev,
                    const double* root_prior_dev, double temperature, int32_t num_simulations, float* obs_dev,
                    int32_t* alive_count_dev, void* stream);
+
+/* n_moves lock-step moves in one call: per move mzs_search_streams on the slots' observations
+ * (obs_dev) and stream seeds, then mzs_arena_step on that search's results.  The loop of
+ * self_play.py:62-73 for every slot at once, enqueued on `stream` without a host synchronisation
+ * (the caller reads *alive_count_dev when it wants to know whether games are still running).
+ * dirichlet_dev / noise_dev / noise_stride: scratch as for mzs_search_streams. */
+int mzs_arena_play(mzs_arena* arena, mzs_handle* h, int32_t n_moves, int32_t num_simulations, int32_t train,
+                   double alpha, double lo, double hi, int32_t prefix_draws, double temperature, float* obs_dev,
+                   double* dirichlet_dev, double* noise_dev, int64_t noise_stride, int32_t* alive_count_dev,
+                   void* stream);
 
 /* ReplayBuffer.sample_batch's per-sample work (replay_buffer.py:147-151: make_image,
  * fill_gap_empty_action, Game.make_target game.py:237-260) for `batch` (row, position) pairs

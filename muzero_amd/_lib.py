@@ -57,6 +57,9 @@ _SIGNATURES = {
     "mzs_search_kernel_name": (C.c_int, [C.c_void_p, C.c_int32, C.c_char_p, C.c_size_t]),
     "mzs_fill_streams": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_double,
                                    C.c_double, C.c_double, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "mzs_search_streams": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_double,
+                                     C.c_double, C.c_double, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_void_p]),
     "mzs_search_injected": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int64, C.c_void_p]),
@@ -90,6 +93,9 @@ _SIGNATURES = {
     "mzs_arena_begin": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p,
                                   C.c_void_p]),
     "mzs_arena_enqueue": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
+    "mzs_arena_play": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double, C.c_double,
+                                 C.c_double, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64,
+                                 C.c_void_p, C.c_void_p]),
     "mzs_arena_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_int32, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
     "mzs_arena_make_batch": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,

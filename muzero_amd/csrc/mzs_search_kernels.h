@@ -67,6 +67,10 @@ struct SearchParams {
     const double* dirichlet;
     const double* noise;
     long long noise_stride;
+    long long noise_avail; /* draws of every game's row that hold data (<= noise_stride): a search that asks
+                              for more sets status[g] and *overflow (mzs_search_streams redoes it) */
+    int* overflow;         /* one flag per handle, or null */
+    int redo;              /* 1: search only the games whose status is set (after a prefix search) */
     const float* t_root_policy;
     const float* t_reward;
     const float* t_value;
@@ -77,6 +81,27 @@ struct SearchParams {
 
 
 typedef void (*quad_kernel_t)(const SearchParams, const QuadLayout);
+
+/* redo launches (SearchParams.redo): true if nothing in this block's games_per_block games asked for
+ * more draws.  Block-uniform, contains a block barrier: call it before any other barrier or return. */
+__device__ __forceinline__ bool redo_skip_block(const SearchParams& p, int games_per_block) {
+    if (!p.redo) return false;
+    if (p.overflow && *p.overflow == 0) return true;
+    const int gb = blockIdx.x * games_per_block;
+    int any = 0;
+    for (int i = threadIdx.x; i < games_per_block; i += blockDim.x)
+        if (gb + i < p.n_games && p.t.status[gb + i]) any = 1;
+    return !__syncthreads_or(any);
+}
+/* the four games of a quad wave: redo them if any of them asked for more (the others replay to the
+ * same results: they never read past the prefix) */
+__device__ __forceinline__ bool redo_skip_quad(const SearchParams& p, int g0) {
+    if (!p.redo) return false;
+    int any = 0;
+    for (int c = 0; c < 4; ++c)
+        if (g0 + c < p.n_games && p.t.status[g0 + c]) any = 1;
+    return !any;
+}
 
 /* bf16 instantiations of k_search_quad (mzsearch_bf16.hip); nullptr: the shape has none */
 quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global);
@@ -234,6 +259,7 @@ __device__ __forceinline__ void quad_write_out(const SearchParams& p, const Quad
         p.t.minmax[2 * (size_t)g] = s.mn;
         p.t.minmax[2 * (size_t)g + 1] = s.mx;
         p.t.status[g] = s.status;
+        if (s.status && p.overflow) *p.overflow = 1;
     }
 }
 
@@ -247,7 +273,8 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
     const Model& m = p.m;
     const int S = p.S;
 
-    /* block-shared tables, register-resident weights, then the only block-level barrier */
+    if (redo_skip_block(p, 4 * (blockDim.x >> 6))) return;
+    /* block-shared tables, register-resident weights, then the only other block-level barrier */
     quad_fill_tables(smem, ql, p);
     typename std::conditional<kB16, QuadWeightsB<SD, NA, H, kMid>, QuadWeights<SD, NA, H, kMid>>::type W;
     if (!kInjected) {
@@ -262,7 +289,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
     __syncthreads();
 
     const int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 4;
-    if (g0 >= p.n_games) return;
+    if (g0 >= p.n_games || redo_skip_quad(p, g0)) return;
     const bool live = g0 + q.c < p.n_games;          /* dead slots replay the last game, write nothing */
     const int g = live ? g0 + q.c : p.n_games - 1;
     /* kHidG: the hidden states of the expansions live in the global SoA array (L2) and LDS keeps
@@ -273,7 +300,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, co
     if constexpr (kHidG) L.hid = L.trunk + 4 * 64 + q.c * 32;
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
-    const int noise_cap = p.noise ? (int)p.noise_stride : 0;
+    const int noise_cap = p.noise ? (int)p.noise_avail : 0;
 
     QuadState s = quad_state_init();
     quad_tree_init(L, q, p.n_nodes);

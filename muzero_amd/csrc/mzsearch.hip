@@ -113,7 +113,8 @@ __global__ void __launch_bounds__(256) k_search_fused(const SearchParams p) {
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int g = blockIdx.x * (blockDim.x >> 6) + wave;
-    if (g >= p.n_games) return; /* no block-level barrier anywhere below */
+    if (redo_skip_block(p, blockDim.x >> 6)) return;
+    if (g >= p.n_games || (p.redo && p.t.status[g] == 0)) return; /* no block-level barrier anywhere below */
     const WaveLds L = carve(smem + (size_t)wave * p.lds.bytes, p.lds);
     const Model& m = p.m;
     const int A = m.A, S = p.S;
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(256) k_search_fused(const SearchParams p) {
     c.g32 = p.g32;
     c.pbc = p.pbc;
     c.noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
-    c.noise_cap = p.noise ? p.noise_stride : 0;
+    c.noise_cap = p.noise ? p.noise_avail : 0;
 
     SearchState s;
     s.mn = __builtin_inff();
@@ -222,6 +223,7 @@ __global__ void __launch_bounds__(256) k_search_fused(const SearchParams p) {
         p.t.minmax[2 * (size_t)g] = s.mn;
         p.t.minmax[2 * (size_t)g + 1] = s.mx;
         p.t.status[g] = s.status;
+        if (s.status && p.overflow) *p.overflow = 1;
     }
 }
 
@@ -244,6 +246,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
     const int wave = threadIdx.x >> 6;
     const Model& m = p.m;
     const int S = p.S;
+    if (redo_skip_block(p, 4 * (blockDim.x >> 6))) return;
 
     /* block-shared tables: pb_c / reciprocals, and the small vectors of the simulation loop */
     quad_fill_tables(smem, ql, p);
@@ -262,7 +265,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
     __syncthreads();
 
     const int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 4;
-    if (g0 >= p.n_games) return;
+    if (g0 >= p.n_games || redo_skip_quad(p, g0)) return;
     const bool live = g0 + q.c < p.n_games;
     const int g = live ? g0 + q.c : p.n_games - 1;
     const QuadLds L = quad_carve(smem, ql, wave, q, false);
@@ -273,7 +276,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
     st.init(p.img, p.n_img, q.lane);
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
-    const int noise_cap = p.noise ? (int)p.noise_stride : 0;
+    const int noise_cap = p.noise ? (int)p.noise_avail : 0;
     float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * p.t.hid_stride;
     float* xrow = B.xin + q.c * kWideX;
 
@@ -338,6 +341,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
     const int wave = threadIdx.x >> 6;
     const Model& m = p.m;
     const int S = p.S, hs = p.t.hid_stride;
+    if (redo_skip_block(p, 4 * (blockDim.x >> 6))) return;
 
     quad_fill_tables(smem, ql, p);
     LstmTabs T;
@@ -357,7 +361,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
     __syncthreads();
 
     const int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 4;
-    if (g0 >= p.n_games) return;
+    if (g0 >= p.n_games || redo_skip_quad(p, g0)) return;
     const bool live = g0 + q.c < p.n_games;
     const int g = live ? g0 + q.c : p.n_games - 1;
     const QuadLds L = quad_carve(smem, ql, wave, q, false);
@@ -368,7 +372,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
     st.init(p.img, p.n_img, q.lane);
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
-    const int noise_cap = p.noise ? (int)p.noise_stride : 0;
+    const int noise_cap = p.noise ? (int)p.noise_avail : 0;
     float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * hs;
     float* xrow = B.xin + q.c * kWideX;
 
@@ -481,13 +485,18 @@ __global__ void __launch_bounds__(256) k_inference(const InferParams p) {
  * dirichlet([alpha] * A) followed by uniform(lo, hi, size = n) — the numbers the reference
  * draws from NumPy's global legacy stream after np.random.seed(seed)
  * (monte_carlo_tree_search.py:140, :163).  MT19937 (init_genrand seeding, 53-bit doubles from
- * two tempered words), legacy standard_gamma for shape <= 1.  One wavefront per game, generator
- * state in LDS; every lane runs the scalar parts redundantly, the state refresh and the uniform
- * fill are spread over the lanes.
+ * two tempered words), legacy standard_gamma for shape <= 1.
+ * One workgroup = sixteen games.  init_genrand is a serial chain of 624 multiply-xorshift steps per
+ * game, so the sixteen chains run side by side in sixteen lanes of wave 0 (states in LDS); then one
+ * wavefront per game: the 624-word state refresh, the gamma draws and the uniform fill are spread
+ * over its lanes.
  * ---------------------------------------------------------------------------- */
 struct FillParams {
     const long long* seeds;
-    int n_games, A, n_uniform, train;
+    const int* redo_status; /* null: every game; else only the games whose entry is set ...        */
+    int* overflow_flag;     /* ... and none at all if this flag (may be null) is zero; a launch for every
+                               game clears it instead                                                  */
+    int n_games, A, n_uniform, train; /* n_uniform: draws written per game (a prefix of the stream) */
     long long stride;
     double alpha, lo, range;
     double* dirichlet;
@@ -495,6 +504,8 @@ struct FillParams {
 };
 
 constexpr int kMtN = 624, kMtM = 397;
+constexpr int kFillGames = 16;       /* games per workgroup of k_fill_streams          */
+constexpr int kMtStride = kMtN + 1;  /* odd stride: the seeding lanes hit distinct banks */
 
 __device__ __forceinline__ unsigned mt_temper(unsigned y) {
     y ^= y >> 11;
@@ -504,18 +515,27 @@ __device__ __forceinline__ unsigned mt_temper(unsigned y) {
     return y;
 }
 
-/* regenerate all 624 words (mt19937_gen of NumPy's legacy generator), 64 at a time */
+/* regenerate all 624 words (mt19937_gen of NumPy's legacy generator), 64 at a time.  Word k needs the
+ * old words k, k+1 and word k+397 (old) or k-227 (new, written at least three chunks earlier): in
+ * ascending chunks every read of a chunk precedes its writes in program order, and LDS operations of
+ * one wave execute in order.  Unrolled: the chunk index is a constant, only chunk 3 (which straddles
+ * 227) and the last one (which ends at 623 and wraps to word 0) keep per-lane selects. */
 __device__ __forceinline__ void mt_twist(unsigned* mt, int lane) {
-    for (int base = 0; base < kMtN; base += kWave) {
-        const int kk = base + lane;
+#pragma unroll
+    for (int c = 0; c < (kMtN + kWave - 1) / kWave; ++c) {
+        const int kk = c * kWave + lane;
+        const bool in = c * kWave + kWave <= kMtN || kk < kMtN;
+        const int k1 = c * kWave + kWave < kMtN ? kk + 1 : (kk + 1 >= kMtN ? 0 : kk + 1);
+        const int ks = c * kWave + kWave <= kMtN - kMtM ? kk + kMtM
+                       : (c * kWave >= kMtN - kMtM ? kk - (kMtN - kMtM)
+                                                   : (kk < kMtN - kMtM ? kk + kMtM : kk - (kMtN - kMtM)));
         unsigned v = 0;
-        if (kk < kMtN) {
-            const unsigned y = (mt[kk] & 0x80000000u) | (mt[kk + 1 == kMtN ? 0 : kk + 1] & 0x7fffffffu);
-            const unsigned src = kk < kMtN - kMtM ? mt[kk + kMtM] : mt[kk - (kMtN - kMtM)];
-            v = src ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        if (in) {
+            const unsigned y = (mt[kk] & 0x80000000u) | (mt[k1] & 0x7fffffffu);
+            v = mt[ks] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
         }
         wave_sync();
-        if (kk < kMtN) mt[kk] = v;
+        if (in) mt[kk] = v;
         wave_sync();
     }
 }
@@ -555,34 +575,80 @@ __device__ __forceinline__ double mt_standard_gamma(MtStream& r, double shape) {
     }
 }
 
-__global__ void __launch_bounds__(256) k_fill_streams(const FillParams p) {
-    __shared__ unsigned mt_s[4][kMtN];
-    __shared__ double gam_s[4][64];
+/* One rejection attempt of legacy_standard_gamma (0 < shape < 1) on the two doubles U, V' it
+ * draws: the value it would return and whether it accepts.  An attempt always consumes exactly
+ * two doubles, so attempt number m of a stream reads words [4m, 4m + 4) whatever happened before. */
+__device__ __forceinline__ bool mt_gamma_attempt(double U, double Vd, double shape, double* X) {
+    /* both arms of the sampler end in pow(., 1 / shape): select the base, call pow once */
+    const double V = -log(1.0 - Vd);
+    const bool low = U <= 1.0 - shape;
+    const double Y = low ? 0.0 : -log((1.0 - U) / shape);
+    *X = pow(low ? U : 1.0 - shape + shape * Y, 1.0 / shape);
+    return *X <= V + Y; /* low arm: X <= V */
+}
+
+__global__ void __launch_bounds__(64 * kFillGames) k_fill_streams(const FillParams p) {
+    __shared__ unsigned mt_s[kFillGames][kMtStride];
+    __shared__ double gam_s[kFillGames][64];
     const int lane = lane_id(), wave = threadIdx.x >> 6;
-    const int g = blockIdx.x * 4 + wave;
-    if (g >= p.n_games) return; /* no block-level barrier below */
-    MtStream r;
-    r.mt = mt_s[wave];
-    r.lane = lane;
-    r.pos = kMtN;
-    if (lane == 0) {
-        unsigned s = (unsigned)p.seeds[g]; /* mt19937_seed: init_genrand */
+    const int g = blockIdx.x * kFillGames + wave;
+    bool mine = g < p.n_games;
+    if (p.redo_status) { /* the games of a prefix search that asked for more; usually none */
+        if (p.overflow_flag && *p.overflow_flag == 0) return;
+        mine = mine && p.redo_status[g] != 0;
+        if (!__syncthreads_or(mine ? 1 : 0)) return;
+    }
+    else if (p.overflow_flag && blockIdx.x == 0 && threadIdx.x == 0) {
+        *p.overflow_flag = 0; /* the search that follows raises it */
+    }
+    /* mt19937_seed (init_genrand) of the block's sixteen games, one per lane */
+    if (wave == 0 && lane < kFillGames && blockIdx.x * kFillGames + lane < p.n_games) {
+        unsigned s = (unsigned)p.seeds[blockIdx.x * kFillGames + lane];
+        unsigned* mt = mt_s[lane];
+#pragma unroll 8
         for (int i = 0; i < kMtN; ++i) {
-            r.mt[i] = s;
+            mt[i] = s;
             s = 1812433253u * (s ^ (s >> 30)) + (unsigned)i + 1u;
         }
     }
-    wave_sync();
+    __syncthreads();
+    if (!mine) return; /* no block-level barrier below */
+    MtStream r;
+    r.mt = mt_s[wave];
+    r.lane = lane;
+    mt_twist(r.mt, lane);
+    r.pos = 0;
     if (p.train) {
         /* RandomState.dirichlet: gamma draws, then normalise by the reciprocal of their sum */
         double* val = gam_s[wave];
-        double acc = 0.0;
-        for (int a = 0; a < p.A; ++a) {
+        int a_done = 0;
+        if (p.alpha < 1.0) {
+            /* lane m evaluates attempt m of the stream (words 4m .. 4m+3 of the first 624): the A gamma
+             * values are the first A accepted attempts, in order */
+            const unsigned w0 = mt_temper(r.mt[4 * lane]) >> 5, w1 = mt_temper(r.mt[4 * lane + 1]) >> 6;
+            const unsigned w2 = mt_temper(r.mt[4 * lane + 2]) >> 5, w3 = mt_temper(r.mt[4 * lane + 3]) >> 6;
+            const double U = ((double)w0 * 67108864.0 + (double)w1) / 9007199254740992.0;
+            const double Vd = ((double)w2 * 67108864.0 + (double)w3) / 9007199254740992.0;
+            double X;
+            const bool ok = mt_gamma_attempt(U, Vd, p.alpha, &X);
+            unsigned long long mask = __builtin_amdgcn_ballot_w64(ok);
+            while (a_done < p.A && mask) {
+                const int mth = __ffsll((long long)mask) - 1;
+                const double v = readlane_f64(X, mth);
+                if (lane == 0) val[a_done] = v;
+                ++a_done;
+                r.pos = 4 * (mth + 1);
+                mask &= mth == 63 ? 0ull : ~((2ull << mth) - 1ull);
+            }
+        }
+        /* shape 1, or (never seen) fewer than A acceptances among 64 attempts: the scalar sampler */
+        for (int a = a_done; a < p.A; ++a) {
             const double v = mt_standard_gamma(r, p.alpha);
             if (lane == 0) val[a] = v;
-            acc += v;
         }
         wave_sync();
+        double acc = 0.0;
+        for (int a = 0; a < p.A; ++a) acc += val[a];
         const double inv = 1.0 / acc;
         for (int a = lane; a < p.A; a += kWave) p.dirichlet[(size_t)g * p.A + a] = val[a] * inv;
     }
@@ -625,6 +691,7 @@ struct mzs_handle {
     float* blob_dev = nullptr;     /* master weights in blob order (include/mzs_layout.h)      */
     int* store_index_dev = nullptr; /* blob element -> offset in the device weight store        */
     double* pbc_dev = nullptr;
+    int* overflow_dev = nullptr;   /* set by a search that ran out of tie-break draws (mzs_search_streams) */
     float* stream_dev = nullptr;   /* chunk images (k_build_stream) of the models that have a quadw / quadl kernel */
     StreamPlan stream_plan;
     /* training (mzs_train_*): allocated by mzs_train_create */
@@ -1059,6 +1126,9 @@ void fill_search_params(mzs_handle* h, SearchParams* p, int n_games, int S, int 
     p->dirichlet = dirichlet;
     p->noise = S > 0 ? noise : nullptr;
     p->noise_stride = stride;
+    p->noise_avail = stride;
+    p->overflow = nullptr;
+    p->redo = 0;
 }
 
 }  // namespace
@@ -1189,6 +1259,10 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
             return fail(MZS_E_HIP, std::string("pbc_table upload: ") + hipGetErrorString(e));
         }
     }
+    if ((rc = dev_alloc(h, &h->overflow_dev, 64))) {
+        mzs_destroy(h);
+        return rc;
+    }
     h->w_search_dev = h->w_dev;
     if (d.precision == MZS_PRECISION_BF16 && (rc = dev_alloc(h, &h->w_search_dev, h->w_floats))) {
         mzs_destroy(h);
@@ -1274,6 +1348,76 @@ int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats) {
     return MZS_OK;
 }
 
+}  // extern "C" (reopened below)
+
+/* the search launch of mzs_search / mzs_search_streams: noise_avail draws of every row hold data;
+ * redo = only the games whose status a previous launch set */
+static int search_launch(mzs_handle* h, int32_t n_games, int32_t S, int32_t train, const float* obs_dev,
+                         const double* dirichlet_dev, const double* noise_dev, int64_t noise_stride,
+                         int64_t noise_avail, int redo, bool build_stream, hipStream_t st) {
+    SearchParams p;
+    fill_search_params(h, &p, n_games, S, train, dirichlet_dev, noise_dev, noise_stride);
+    p.obs = obs_dev;
+    p.noise_avail = noise_avail;
+    p.overflow = h->overflow_dev;
+    p.redo = redo;
+    const SearchPlan plan = plan_search(h, S);
+    if (plan.kind == kPlanGeneric) return launch(k_search_fused<false>, p, n_games, p.lds, st);
+    if (plan.kind == kPlanStream) {
+        if (build_stream) {
+            hipLaunchKernelGGL(k_build_stream, dim3(h->stream_plan.n), dim3(256), 0, st, h->w_search_dev,
+                               h->stream_plan, h->stream_dev);
+            HIP_TRY(hipGetLastError());
+        }
+        p.img = h->stream_dev;
+        p.n_img = h->stream_plan.n;
+        p.first_img = h->stream_plan.first;
+    }
+    return launch_quad(plan.kernel, p, plan.ql, plan.wpb, st);
+}
+
+static int fill_launch(mzs_handle* h, int32_t n_games, int32_t train, const int64_t* seeds_dev, double alpha, double lo,
+                       double hi, double* dirichlet_dev, double* noise_dev, int64_t noise_stride, int64_t n_draws,
+                       const int* redo_status, hipStream_t st) {
+    FillParams p;
+    p.seeds = reinterpret_cast<const long long*>(seeds_dev);
+    p.redo_status = redo_status;
+    p.overflow_flag = h->overflow_dev;
+    p.n_games = n_games;
+    p.A = h->cfg.dims.n_actions;
+    p.n_uniform = (int)n_draws;
+    p.train = train;
+    p.stride = noise_stride;
+    p.alpha = alpha;
+    p.lo = lo;
+    p.range = hi - lo;
+    p.dirichlet = dirichlet_dev;
+    p.noise = noise_dev;
+    hipLaunchKernelGGL(k_fill_streams, dim3((n_games + kFillGames - 1) / kFillGames), dim3(64 * kFillGames), 0, st, p);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
+static int check_fill_args(mzs_handle* h, int32_t n_games, int32_t num_simulations, int32_t train,
+                           const int64_t* seeds_dev, double alpha, const double* dirichlet_dev,
+                           const double* noise_dev, int64_t noise_stride) {
+    if (!h) return fail(MZS_E_ARG, "null handle");
+    if (n_games < 0 || num_simulations < 0) return fail(MZS_E_ARG, "bad sizes");
+    const int64_t n_u = mzs_max_draws(h->cfg.dims.n_actions, num_simulations);
+    if (!seeds_dev || (n_u > 0 && (!noise_dev || noise_stride < n_u)))
+        return fail(MZS_E_ARG, "seeds / noise buffer missing or noise_stride < mzs_max_draws(A, S)");
+    const int do_dir = train && num_simulations > 0;
+    if (do_dir && !dirichlet_dev) return fail(MZS_E_ARG, "train=1 needs dirichlet_dev");
+    if (do_dir && !(alpha > 0.0 && alpha <= 1.0))
+        return fail(MZS_E_ARG, "device Dirichlet implements NumPy's legacy gamma sampler for 0 < alpha <= 1 "
+                               "only (draw the streams on the host for larger alpha)");
+    if (h->cfg.dims.n_actions > 64) return fail(MZS_E_ARG, "device Dirichlet holds one gamma per lane: n_actions <= 64");
+    if (n_u >= (1ll << 31)) return fail(MZS_E_ARG, "stream too long");
+    return MZS_OK;
+}
+
+extern "C" {
+
 int mzs_search(mzs_handle* h, int32_t n_games, int32_t S, int32_t train, const float* obs_dev,
                const double* dirichlet_dev, const double* noise_dev, int64_t noise_stride,
                void* stream) {
@@ -1283,21 +1427,43 @@ int mzs_search(mzs_handle* h, int32_t n_games, int32_t S, int32_t train, const f
     if (!obs_dev) return fail(MZS_E_ARG, "obs_dev is null");
     if (n_games == 0) return MZS_OK;
     HIP_TRY(hipSetDevice(h->cfg.device));
-    SearchParams p;
-    fill_search_params(h, &p, n_games, S, train, dirichlet_dev, noise_dev, noise_stride);
-    p.obs = obs_dev;
-    const SearchPlan plan = plan_search(h, S);
+    return search_launch(h, n_games, S, train, obs_dev, dirichlet_dev, noise_dev, noise_stride, noise_stride, 0, true,
+                         static_cast<hipStream_t>(stream));
+}
+
+/* One move's searches with their random streams made on the device, lazily: the Dirichlet rows and
+ * the first prefix_draws tie-break draws of every game, the search, and then, for the games whose
+ * search asked for more than the prefix (status), the whole stream and the search again.  Two
+ * launches more than fill + search, both of which leave at once when no game asked.  Results are
+ * those of mzs_fill_streams + mzs_search, bit for bit. */
+int mzs_search_streams(mzs_handle* h, int32_t n_games, int32_t S, int32_t train, const float* obs_dev,
+                       const int64_t* seeds_dev, double alpha, double lo, double hi, int32_t prefix_draws,
+                       double* dirichlet_dev, double* noise_dev, int64_t noise_stride, void* stream) {
+    int rc = check_fill_args(h, n_games, S, train, seeds_dev, alpha, dirichlet_dev, noise_dev, noise_stride);
+    if (rc) return rc;
+    if ((rc = check_search_args(h, n_games, S, train, dirichlet_dev, noise_dev, noise_stride))) return rc;
+    if (!h->have_weights) return fail(MZS_E_STATE, "mzs_set_weights has not been called");
+    if (!obs_dev) return fail(MZS_E_ARG, "obs_dev is null");
+    if (n_games == 0) return MZS_OK;
+    HIP_TRY(hipSetDevice(h->cfg.device));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (plan.kind == kPlanGeneric) return launch(k_search_fused<false>, p, n_games, p.lds, st);
-    if (plan.kind == kPlanStream) {
-        hipLaunchKernelGGL(k_build_stream, dim3(h->stream_plan.n), dim3(256), 0, st, h->w_search_dev, h->stream_plan,
-                           h->stream_dev);
-        HIP_TRY(hipGetLastError());
-        p.img = h->stream_dev;
-        p.n_img = h->stream_plan.n;
-        p.first_img = h->stream_plan.first;
-    }
-    return launch_quad(plan.kernel, p, plan.ql, plan.wpb, st);
+    const int A = h->cfg.dims.n_actions;
+    const int64_t n_u = mzs_max_draws(A, S);
+    /* default prefix: nine levels per simulation, about twice what a search of these sizes consumes
+     * (with the Dirichlet's words: three refreshes of the 624-word generator state at A = 2, S = 50) */
+    int64_t prefix = prefix_draws > 0 ? prefix_draws : (int64_t)9 * A * S;
+    prefix = prefix < n_u ? prefix : n_u;
+    const int do_dir = train && S > 0;
+    if ((rc = fill_launch(h, n_games, do_dir, seeds_dev, alpha, lo, hi, dirichlet_dev, noise_dev, noise_stride, prefix,
+                          nullptr, st)))
+        return rc;
+    if ((rc = search_launch(h, n_games, S, train, obs_dev, dirichlet_dev, noise_dev, noise_stride, prefix, 0, true, st)))
+        return rc;
+    if (prefix == n_u) return MZS_OK;
+    if ((rc = fill_launch(h, n_games, do_dir, seeds_dev, alpha, lo, hi, dirichlet_dev, noise_dev, noise_stride, n_u,
+                          h->tree.status, st)))
+        return rc;
+    return search_launch(h, n_games, S, train, obs_dev, dirichlet_dev, noise_dev, noise_stride, n_u, 1, false, st);
 }
 
 int mzs_search_kernel_name(mzs_handle* h, int32_t num_simulations, char* name_out, size_t name_size) {
@@ -1868,36 +2034,14 @@ int mzs_get_weights(mzs_handle* h, float* blob_out, size_t n_floats) {
 int mzs_fill_streams(mzs_handle* h, int32_t n_games, int32_t num_simulations, int32_t train,
                      const int64_t* seeds_dev, double alpha, double lo, double hi,
                      double* dirichlet_dev, double* noise_dev, int64_t noise_stride, void* stream) {
-    if (!h) return fail(MZS_E_ARG, "null handle");
-    if (n_games < 0 || num_simulations < 0) return fail(MZS_E_ARG, "bad sizes");
-    const int A = h->cfg.dims.n_actions;
-    const int64_t n_u = mzs_max_draws(A, num_simulations);
-    if (!seeds_dev || (n_u > 0 && (!noise_dev || noise_stride < n_u)))
-        return fail(MZS_E_ARG, "seeds / noise buffer missing or noise_stride < mzs_max_draws(A, S)");
-    const int do_dir = train && num_simulations > 0;
-    if (do_dir && !dirichlet_dev) return fail(MZS_E_ARG, "train=1 needs dirichlet_dev");
-    if (do_dir && !(alpha > 0.0 && alpha <= 1.0))
-        return fail(MZS_E_ARG, "device Dirichlet implements NumPy's legacy gamma sampler for 0 < alpha <= 1 "
-                               "only (draw the streams on the host for larger alpha)");
-    if (n_u >= (1ll << 31)) return fail(MZS_E_ARG, "stream too long");
+    const int rc = check_fill_args(h, n_games, num_simulations, train, seeds_dev, alpha, dirichlet_dev, noise_dev,
+                                   noise_stride);
+    if (rc) return rc;
     if (n_games == 0) return MZS_OK;
     HIP_TRY(hipSetDevice(h->cfg.device));
-    FillParams p;
-    p.seeds = reinterpret_cast<const long long*>(seeds_dev);
-    p.n_games = n_games;
-    p.A = A;
-    p.n_uniform = (int)n_u;
-    p.train = do_dir;
-    p.stride = noise_stride;
-    p.alpha = alpha;
-    p.lo = lo;
-    p.range = hi - lo;
-    p.dirichlet = dirichlet_dev;
-    p.noise = noise_dev;
-    hipLaunchKernelGGL(k_fill_streams, dim3((n_games + 3) / 4), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), p);
-    HIP_TRY(hipGetLastError());
-    return MZS_OK;
+    return fill_launch(h, n_games, train && num_simulations > 0, seeds_dev, alpha, lo, hi, dirichlet_dev, noise_dev,
+                       noise_stride, mzs_max_draws(h->cfg.dims.n_actions, num_simulations), nullptr,
+                       static_cast<hipStream_t>(stream));
 }
 
 }  // extern "C" (reopened below)
@@ -2009,6 +2153,26 @@ int mzs_arena_step(mzs_arena* ar, const int32_t* visits_dev, const float* root_v
                        root_value_dev, root_prior_dev, temperature, num_simulations < 1 ? 1 : 0, obs_dev);
     hipLaunchKernelGGL(k_arena_refill, dim3(1), dim3(kRefillThreads), 0, st, ar->a, obs_dev, alive_count_dev);
     HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
+int mzs_arena_play(mzs_arena* ar, mzs_handle* h, int32_t n_moves, int32_t num_simulations, int32_t train,
+                   double alpha, double lo, double hi, int32_t prefix_draws, double temperature, float* obs_dev,
+                   double* dirichlet_dev, double* noise_dev, int64_t noise_stride, int32_t* alive_count_dev,
+                   void* stream) {
+    if (!ar || !h) return fail(MZS_E_ARG, "null argument");
+    if (n_moves < 0) return fail(MZS_E_ARG, "bad move count");
+    if (ar->cfg.device != h->cfg.device) return fail(MZS_E_ARG, "arena and search handle live on different devices");
+    if (ar->a.G > h->cfg.max_games) return fail(MZS_E_ARG, "the arena has more slots than the handle has games");
+    for (int m = 0; m < n_moves; ++m) {
+        int rc = mzs_search_streams(h, ar->a.G, num_simulations, train, obs_dev,
+                                    reinterpret_cast<const int64_t*>(ar->a.stream_seed), alpha, lo, hi, prefix_draws,
+                                    dirichlet_dev, noise_dev, noise_stride, stream);
+        if (rc) return rc;
+        if ((rc = mzs_arena_step(ar, h->res.visits, h->res.root_value, h->res.root_prior, temperature, num_simulations,
+                                 obs_dev, alive_count_dev, stream)))
+            return rc;
+    }
     return MZS_OK;
 }
 

@@ -60,6 +60,8 @@ class SearchEngine:
         self.h = h
         self.n_games = 0
         self.num_simulations = 0
+        self.stream_prefix = 0          # search_streams: draws written before the search (0: library default)
+        self.num_simulations = 0
         self.has_weights = False
 
     def close(self):
@@ -139,6 +141,52 @@ class SearchEngine:
                                              float(lo), float(hi), _ptr(dirichlet), _ptr(noise), stride,
                                              self._stream()), "mzs_fill_streams")
         self._keep_seeds = seeds
+        return dirichlet, noise
+
+    def stream_scratch(self, n_games, num_simulations):
+        """(dirichlet [G, A], noise [G, max_draws]) f64 device scratch of search_streams, reused move
+        after move."""
+        stride = max(1, rng.max_draws(self.A, int(num_simulations)))
+        key = (int(n_games), stride)
+        if getattr(self, "_stream_scratch_key", None) != key:
+            self._stream_scratch = (torch.empty((key[0], self.A), dtype=torch.float64, device=self.device),
+                                    torch.empty(key, dtype=torch.float64, device=self.device))
+            self._stream_scratch_key = key
+        return self._stream_scratch
+
+    def adapt_stream_prefix(self):
+        """Host-side tuning of search_streams' prefix (a host sync: call it where the loop already
+        reads something back).  A redo pass costs a whole search however few games need it, so the
+        prefix should cover every game of a move almost always: 1.5 x the largest consumption of the
+        last search, in whole refreshes of the generator state (312 draws), never below the library
+        default.  Purely a speed knob: any prefix gives the same results."""
+        if self.n_games == 0 or self.num_simulations == 0:
+            return self.stream_prefix
+        used = int(self.results()["consumed"][: self.n_games].max().item())
+        want = -(-int(1.5 * used) // 312) * 312
+        self.stream_prefix = max(want, 9 * self.A * self.num_simulations)
+        return self.stream_prefix
+
+    def search_streams(self, obs, seeds, num_simulations, train=True, lo=1e-7, hi=2e-7, prefix_draws=None):
+        """fill_streams + search as one call that writes only a prefix of every game's stream and
+        redoes, on the device, the few searches that ask for more (mzs_search_streams).  Same results
+        as search(obs, *fill_streams(seeds, ...)), bit for bit.  Returns the scratch tensors
+        (dirichlet, noise): only the prefix of a noise row is defined unless its game was redone.
+        prefix_draws None: self.stream_prefix (0 = the library default, see adapt_stream_prefix)."""
+        if prefix_draws is None:
+            prefix_draws = self.stream_prefix
+        obs = self._dev(obs, torch.float32)
+        seeds = self._dev(np.asarray(seeds, dtype=np.int64) if not isinstance(seeds, torch.Tensor) else seeds,
+                          torch.int64)
+        G, S = obs.shape[0], int(num_simulations)
+        assert obs.shape == (G, self.obs_dim) and seeds.shape == (G,)
+        dirichlet, noise = self.stream_scratch(G, S)
+        stride = noise.shape[1]
+        self._keep = (obs, seeds)
+        _lib.check(self.lib.mzs_search_streams(self.h, G, S, int(bool(train)), _ptr(obs), _ptr(seeds), self.alpha,
+                                               float(lo), float(hi), int(prefix_draws), _ptr(dirichlet), _ptr(noise),
+                                               stride, self._stream()), "mzs_search_streams")
+        self.n_games, self.num_simulations = G, S
         return dirichlet, noise
 
     def search_injected(self, table, dirichlet, noise, num_simulations, train=True):
@@ -254,7 +302,8 @@ class SearchEngine:
         after np.random.seed(seed)), search, and return host arrays."""
         S = self.max_simulations if num_simulations is None else int(num_simulations)
         if noise is None and 0.0 < self.alpha <= 1.0:
-            dirichlet, noise = self.fill_streams(seeds, S, train)          # on the device
+            self.search_streams(observations, seeds, S, train)             # streams made on the device
+            return self.results_host()
         elif noise is None:
             dirichlet, noise = rng.noise_streams(seeds, self.A, S, self.alpha, train)
         self.search(observations, dirichlet if (train and S > 0) else None,

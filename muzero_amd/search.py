@@ -150,16 +150,19 @@ class Monte_carlo_tree_search:
         G, A = obs.shape[0], model.dims[1]
         noisy = bool(train) and S > 0
         eng = self._engine_for(model, G, S)
+        searched = False
         if S > 0 and noise is None:
             if seeds is None:
                 raise ValueError("run_batch needs seeds or explicit dirichlet/noise streams")
             if 0.0 < self.root_dirichlet_alpha <= 1.0:
-                # generated on the GPU (mzs_fill_streams): the host loop over RandomState objects
+                # generated on the GPU (mzs_search_streams): the host loop over RandomState objects
                 # costs ~0.16 ms per game, three orders of magnitude more than the search itself
-                dirichlet, noise = eng.fill_streams(seeds, S, train)
+                eng.search_streams(obs, seeds, S, train)
+                searched = True
             else:
                 dirichlet, noise = rng.noise_streams(seeds, A, S, self.root_dirichlet_alpha, train)
-        eng.search(obs, dirichlet if noisy else None, noise if S > 0 else None, S, train)
+        if not searched:
+            eng.search(obs, dirichlet if noisy else None, noise if S > 0 else None, S, train)
         out = eng.results_host()
         tree = eng.tree_host() if want_tree else {}
         if want_tree and tree["status"].any():

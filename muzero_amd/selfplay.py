@@ -4,7 +4,7 @@
 The reference plays ONE game at a time through Python objects (Game lists, one MCTS per move,
 ReplayBuffer of Game objects).  Here G episodes advance in lock step on one GPU:
 
-  per move   fill_streams -> mzs_search (G trees) -> mzs_arena_step (store_search_statistics,
+  per move   mzs_search_streams (streams + G trees) -> mzs_arena_step (store_search_statistics,
              policy_step, env.step and the trajectory append, all in HBM)       self_play.py:62-73
   per round  finished trajectories stay in HBM rows; the host keeps only what the reference's
              ReplayBuffer needs to SAMPLE: lengths and priorities (ReplayStore)  replay_buffer.py
@@ -375,6 +375,17 @@ class Arena:
                                            _ptr(r["root_prior"]), float(temperature), S, _ptr(self.obs),
                                            _ptr(self.alive_count), self.eng._stream()), "mzs_arena_step")
 
+    def play(self, n_moves, num_simulations, temperature, train=True, lo=1e-7, hi=2e-7):
+        """n_moves x (search with device-made streams, step) in one library call (mzs_arena_play):
+        nothing but kernel launches between the moves."""
+        e, S = self.eng, int(num_simulations)
+        dirichlet, noise = e.stream_scratch(self.G, S)
+        _lib.check(self.lib.mzs_arena_play(self.h, e.h, int(n_moves), S, int(bool(train)), e.alpha, float(lo),
+                                           float(hi), int(e.stream_prefix), float(temperature), _ptr(self.obs),
+                                           _ptr(dirichlet), _ptr(noise), noise.shape[1], _ptr(self.alive_count),
+                                           e._stream()), "mzs_arena_play")
+        e.n_games, e.num_simulations = self.G, S
+
     def priority(self, row0, n_rows, td_steps, discount, longest):
         """Game.make_priority for rows [row0, row0 + n_rows) on the device: float64 tensor
         [n_rows, longest] (longest = the longest game among those rows)."""
@@ -419,23 +430,18 @@ def play_round(engine, arena, seeds, episode, num_simulations, temperature, row0
     obs = arena.begin(row0, seeds, episode)
     S = int(num_simulations)
     moves = 0
-    for _ in range(arena.n_games * arena.T):
-        dirichlet, noise = engine.fill_streams(arena.arrays["stream_seed"], S, train)
-        engine.search(obs, dirichlet, noise if S > 0 else None, S, train)
-        arena.step(temperature)
-        moves += 1
-        if moves % check_every == 0 and int(arena.alive_count.item()) == 0:
+    while moves < arena.n_games * arena.T:
+        arena.play(check_every, S, temperature, train)
+        moves += check_every
+        engine.adapt_stream_prefix()
+        if int(arena.alive_count.item()) == 0:
             break
     return moves
 
 
 def play_moves(engine, arena, n_moves, num_simulations, temperature, train=True):
     """n_moves lock-step moves, enqueued without a host sync."""
-    S = int(num_simulations)
-    for _ in range(int(n_moves)):
-        dirichlet, noise = engine.fill_streams(arena.arrays["stream_seed"], S, train)
-        engine.search(arena.obs, dirichlet, noise if S > 0 else None, S, train)
-        arena.step(temperature)
+    arena.play(n_moves, num_simulations, temperature, train)
 
 
 def play_until(engine, arena, done_upto, num_simulations, temperature, check_every=16, train=True, max_moves=None):
@@ -449,6 +455,7 @@ def play_until(engine, arena, done_upto, num_simulations, temperature, check_eve
     while q[2] < done_upto and moves < limit:
         play_moves(engine, arena, check_every, S, temperature, train)
         moves += check_every
+        engine.adapt_stream_prefix()
         q = arena.queue_state()
         if int(arena.alive_count.item()) == 0 and q[0] >= q[1]:
             break                       # nothing running, nothing queued

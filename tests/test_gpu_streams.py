@@ -63,3 +63,77 @@ def test_run_batch_with_device_streams_matches_oracle():
     same_bits = np.all(dirichlet.cpu().numpy().view(np.uint64) == hd.view(np.uint64), axis=1)
     assert same_bits.mean() > 0.5
     assert np.array_equal(ref["visits"][same_bits], host["visits"][same_bits])
+
+
+def _search_both_ways(shape, blob, G, S, prefix, seed0=500, scale=0.05):
+    """(fill_streams + search) and search_streams(prefix) on the same handle: results and trees.
+    prefix "median": the median number of draws the searches consume (half of them overflow)."""
+    from muzero_amd.engine import SearchEngine
+    eng = SearchEngine(shape, max_games=G, max_simulations=S, discount=0.997)
+    eng.set_weights(blob)
+    obs = np.random.RandomState(seed0).uniform(-scale, scale, size=(G, shape[0])).astype(np.float32)
+    seeds = np.arange(G, dtype=np.int64) + seed0
+    dirichlet, noise = eng.fill_streams(seeds, S, True)
+    eng.search(obs, dirichlet, noise, S, True)
+    full, full_tree = eng.results_host(), eng.tree_host()
+    if prefix == "median":
+        prefix = int(np.median(full["consumed"]))
+    eng.search_streams(obs, seeds, S, True, prefix_draws=prefix)
+    lazy, lazy_tree = eng.results_host(), eng.tree_host()
+    name = eng.search_kernel_name(S)
+    eng.close()
+    return full, full_tree, lazy, lazy_tree, name, prefix
+
+
+@pytest.mark.parametrize("model,G,S,prefixes", [
+    ("tag123", 203, 50, (0, "median", 8)),      # k_search_quad (register-resident weights)
+    ("synA4", 45, 20, (0, "median", 4)),        # four actions
+    ("lstmA", 37, 30, (0, "median")),           # k_search_quadl (weight stream: redo skips k_build_stream)
+])
+def test_search_streams_equals_fill_plus_search(model, G, S, prefixes):
+    """mzs_search_streams writes a prefix of every stream and redoes the searches that ask for more:
+    the end state must be that of mzs_fill_streams + mzs_search bit for bit, whether no game, some
+    games or every game overflows its prefix."""
+    d, blob = fixture_weights(model)
+    shape = (d.obs_dim, d.n_actions, d.state_dim, d.hidden_dim, d.n_mid_layers, d.model_kind)
+    for prefix in prefixes:
+        asked = prefix
+        full, ft, lazy, lt, name, prefix = _search_both_ways(shape, blob, G, S, prefix)
+        over = int((full["consumed"] > (prefix if prefix > 0 else 9 * d.n_actions * S)).sum())
+        print(f"\n{model} {name} prefix={prefix}: {over}/{G} searches redone, "
+              f"draws consumed mean {full['consumed'].mean():.0f} max {full['consumed'].max()}")
+        assert np.all(lt["status"] == 0) and np.all(ft["status"] == 0)
+        for k in ("visits", "consumed", "path_len"):
+            assert np.array_equal(full[k], lazy[k]), (prefix, k)
+        assert np.array_equal(full["root_value"].view(np.uint32), lazy["root_value"].view(np.uint32))
+        assert np.array_equal(full["root_prior"].view(np.uint64), lazy["root_prior"].view(np.uint64))
+        for k in ("visit", "child_base", "sim_leaf"):
+            assert np.array_equal(ft[k], lt[k]), (prefix, k)
+        for k in ("value_sum", "prior", "reward", "minmax", "hidden"):
+            assert np.array_equal(ft[k].view(np.uint32), lt[k].view(np.uint32)), (prefix, k)
+        if asked in (4, 8):
+            assert over == G                 # every search was redone
+        if asked == "median":
+            assert 0 < over < G              # a mixed case: redone and untouched quads side by side
+
+
+def test_search_streams_generic_kernel_and_bf16():
+    """The one-game-per-wave kernel (a shape without a quad kernel) and the bf16 quad kernel."""
+    from muzero_amd.model import blob_layout
+    rs = np.random.RandomState(77)
+    shape = (6, 3, 20, 48, 1)                      # no compile-time instantiation: k_search_fused
+    n_w = sum(int(np.prod(shp)) for _, shp in blob_layout(*shape))
+    blob = (rs.standard_normal(n_w) * 0.3).astype(np.float32)
+    for prefix in (0, "median"):
+        full, ft, lazy, lt, name, _ = _search_both_ways(shape, blob, 29, 16, prefix, scale=1.0)
+        assert "fused" in name
+        assert np.array_equal(full["visits"], lazy["visits"]) and np.array_equal(full["consumed"], lazy["consumed"])
+        assert np.array_equal(full["root_value"].view(np.uint32), lazy["root_value"].view(np.uint32))
+        assert np.array_equal(ft["visit"], lt["visit"]) and np.all(lt["status"] == 0)
+    d, blob = fixture_weights("tag123")
+    shape = (d.obs_dim, d.n_actions, d.state_dim, d.hidden_dim, d.n_mid_layers, 0, 1)
+    for prefix in (0, "median"):
+        full, ft, lazy, lt, name, _ = _search_both_ways(shape, blob, 64, 50, prefix)
+        assert np.array_equal(full["visits"], lazy["visits"]) and np.array_equal(full["consumed"], lazy["consumed"])
+        assert np.array_equal(full["root_value"].view(np.uint32), lazy["root_value"].view(np.uint32))
+        assert np.array_equal(ft["visit"], lt["visit"]) and np.all(lt["status"] == 0)

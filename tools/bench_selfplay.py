@@ -33,52 +33,61 @@ def main():
     dims = (4, 2, 31, 64, 0)
     eng = SearchEngine(dims, max_games=G, max_simulations=S, discount=0.997)
     n = eng.weight_count()
-    eng.set_weights((np.random.RandomState(0).standard_normal(n) * 0.1).astype(np.float32))
+    w0 = (np.random.RandomState(0).standard_normal(n) * 0.1).astype(np.float32)
+    eng.set_weights(w0)
     K, td = 5, 10
     tr = Trainer(eng, K, a.batch, "adam", 1e-3)
     N = a.games_per_round or 8 * G
-    store = ReplayStore(window_size=N, batch_size=a.batch, num_unroll=K, td_steps=td, discount=0.997)
-    ar = Arena(eng, G, (4 if a.rolling else 3) * N, T)
-    loop = SelfPlay(None, eng, tr, ar, store, S, games_per_iteration=N, seed=1, rolling=a.rolling)
-    np.random.seed(0)
-    out = []
-    for r in range(a.rounds):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        if r == a.rounds - 1 and not a.rolling:          # last round: time the device loop alone
-            seeds = (np.arange(N, dtype=np.int64) * 2654435761 + 99) & 0x7FFFFFFF
-            mv = play_round(eng, ar, seeds, 1000 + r, S, 1.0, loop.block * N)
+
+    def run_once():
+        eng.set_weights(w0)        # both passes play the same games (the optimizer state carries over, harmless)
+        store = ReplayStore(window_size=N, batch_size=a.batch, num_unroll=K, td_steps=td, discount=0.997)
+        ar = Arena(eng, G, (4 if a.rolling else 3) * N, T)
+        loop = SelfPlay(None, eng, tr, ar, store, S, games_per_iteration=N, seed=1, rolling=a.rolling)
+        np.random.seed(0)
+        out = []
+        for r in range(a.rounds):
             torch.cuda.synchronize()
-            tl = time.perf_counter() - t0
-            n_moves = int(ar.arrays["length"][loop.block * N:(loop.block + 1) * N].sum().item())
-            out.append(dict(loop_only=True, loop_s=tl, loop_moves=mv, ms_per_lockstep_move=tl * 1e3 / mv,
-                            game_moves=n_moves, sims_per_s=n_moves * S / tl))
             t0 = time.perf_counter()
-        rewards = loop.play(1.0, 1.0 if (a.rolling and r < a.rounds - 1) else None)
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        moves = int(rewards.sum())
-        longest = loop.lockstep_moves
-        for _ in range(a.train_steps):
-            loss = loop.train_step()
-        torch.cuda.synchronize()
-        t2 = time.perf_counter()
-        out.append(dict(round=r, play_s=t1 - t0, game_moves=moves, longest=longest,
-                        moves_per_s=moves / (t1 - t0), slot_utilisation=moves / (longest * G),
-                        sims_per_s=moves * S / (t1 - t0), search_sims_per_s=longest * G * S / (t1 - t0), train_ms_per_step=(t2 - t1) * 1e3 / a.train_steps,
-                        mean_reward=float(rewards.mean()), loss=float(loss.item())))
-    # rolling rounds: a round's lock-step moves also advance the NEXT round's early games, so the
-    # per-round utilisation is taken over the whole run: game moves recorded / (lock-step moves x slots)
-    # (the first round carries the one-time costs — module load, kernel attribute calls — so it is
-    # left out when there are later rounds)
+            if r == a.rounds - 1 and not a.rolling:          # last round: time the device loop alone
+                seeds = (np.arange(N, dtype=np.int64) * 2654435761 + 99) & 0x7FFFFFFF
+                mv = play_round(eng, ar, seeds, 1000 + r, S, 1.0, loop.block * N)
+                torch.cuda.synchronize()
+                tl = time.perf_counter() - t0
+                n_moves = int(ar.arrays["length"][loop.block * N:(loop.block + 1) * N].sum().item())
+                out.append(dict(loop_only=True, loop_s=tl, loop_moves=mv, ms_per_lockstep_move=tl * 1e3 / mv,
+                                game_moves=n_moves, sims_per_s=n_moves * S / tl))
+                t0 = time.perf_counter()
+            rewards = loop.play(1.0, 1.0 if (a.rolling and r < a.rounds - 1) else None)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            moves = int(rewards.sum())
+            longest = loop.lockstep_moves
+            for _ in range(a.train_steps):
+                loss = loop.train_step()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            out.append(dict(round=r, play_s=t1 - t0, game_moves=moves, lockstep_moves=longest,
+                            ms_per_lockstep_move=(t1 - t0) * 1e3 / longest,
+                            train_ms_per_step=(t2 - t1) * 1e3 / a.train_steps,
+                            mean_reward=float(rewards.mean()), loss=float(loss.item())))
+        ar.close()
+        return out
+
+    run_once()            # warm-up pass: module load, kernel attribute calls, allocator growth
+    out = run_once()
+    # Totals over ALL rounds of the measured pass.  With rolling rounds a round's lock-step moves also
+    # advance the next round's early games, so only the totals mean something: game moves recorded /
+    # (lock-step moves x slots); the last round's tail drains unrefilled and is part of the figure.
     rr = [o for o in out if "round" in o]
-    rr = rr[1:] if len(rr) > 1 else rr
     tot_moves = sum(o["game_moves"] for o in rr)
-    tot_lock = sum(o["longest"] for o in rr)
+    tot_lock = sum(o["lockstep_moves"] for o in rr)
     tot_play = sum(o["play_s"] for o in rr)
     print(json.dumps(dict(games_per_round=N, slots=G, sims=S, max_moves=T, batch=a.batch, rolling=a.rolling,
-                          slot_utilisation=tot_moves / (tot_lock * G), useful_sims_per_s=tot_moves * S / tot_play,
-                          search_sims_per_s=tot_lock * G * S / tot_play, rounds=out)))
+                          rounds_timed=len(rr), slot_utilisation=tot_moves / (tot_lock * G),
+                          useful_sims_per_s=tot_moves * S / tot_play,
+                          search_sims_per_s=tot_lock * G * S / tot_play,
+                          ms_per_lockstep_move=tot_play * 1e3 / tot_lock, rounds=out)))
 
 
 if __name__ == "__main__":
