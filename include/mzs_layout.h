@@ -36,7 +36,8 @@ typedef struct mzs_dims {
     int32_t hidden_dim;   /* H                                               */
     int32_t n_mid_layers; /* L: how many times the tied mid layer is applied (MLP);
                              num_layers of every nn.LSTM (LSTM model, 1..MZS_LSTM_MAX_LAYERS) */
-    int32_t model_kind;   /* MZS_MODEL_MLP (0, 'mlp_model') or MZS_MODEL_LSTM ('lstm_model')    */
+    int32_t model_kind;   /* MZS_MODEL_MLP (0, 'mlp_model'), MZS_MODEL_LSTM ('lstm_model') or
+                             MZS_MODEL_VISION ('vision_model', inference entry points only)     */
     int32_t precision;    /* MZS_PRECISION_F32 (0) or MZS_PRECISION_BF16: Muzero(type_format=...),
                              muzero_model.py:194-204.  bf16 = weights and layer inputs rounded to
                              bfloat16, fp32 accumulation and epilogues (include/mzs_numeric.h)   */
@@ -139,9 +140,118 @@ static inline mzs_lstm_offsets mzs_lstm_layout(const mzs_dims* d) {
     return o;
 }
 
-/* floats in the weight blob of either model kind */
+/* 'vision_model' (neural_network_vision_model.py:41-300): ResNet-v2 blocks on a 98 x 98 x 3 image
+ * (muzero_model.py:312-314), hidden state = 3 x 7 x 7 feature map, MLP heads on its 147 values.
+ * mzs_dims: obs_dim = 98 (image side), state_dim = support size of the value / reward heads,
+ * hidden_dim = H and n_mid_layers = L of the head MLPs (L >= 1 is also the number of times the
+ * dynamics / prediction residual block is applied, :214, :284).
+ * Blob: every DISTINCT tensor once (the reference's Sequentials repeat one Residual_block, one
+ * BatchNorm2d and one Linear object in several places), conv weights [out][in][ky][kx]:
+ *   residual block (:41-82): conv_a = `convolution_1` (first and last conv of the block), conv_b =
+ *     `convolution_3` (the middle one), then the one BatchNorm2d: weight, bias, running_mean,
+ *     running_var;   y = x + conv_a(R(conv_b(R(conv_a(R(x))))))  with R = relu(batchnorm(.))
+ *   representation: Down_sample (:84-122): conv_in 3->1 stride 2, res_in x2, conv_out 1->3 stride 2,
+ *     res_out x2, avgpool 3/2/1, res_out x3, avgpool; then res (:147-149).  The tensors of the
+ *     unused down_sampling=False path (:141-142) follow, for checkpoint fidelity.
+ *   dynamics (:167-230): conv 4->3, batchnorm, relu, res x L, relu -> next state; reward: 1x1 conv
+ *     4->3 (+bias), flatten, Linear 147->H, relu, (Linear H->H, relu) x L [one tensor], Linear H->Sd.
+ *     Input channel 3 is the action plane, constant (a + 1) / A (muzero_model.py:505-516).
+ *   prediction (:234-300): res x L, then value and policy: 1x1 conv 3->3 (+bias), flatten, MLP. */
+#define MZS_MODEL_VISION 2
+#define MZS_VIS_C 3
+#define MZS_VIS_SIDE 98
+#define MZS_VIS_S1 49
+#define MZS_VIS_S2 25
+#define MZS_VIS_S3 13
+#define MZS_VIS_S4 7
+#define MZS_VIS_HIDDEN (MZS_VIS_C * MZS_VIS_S4 * MZS_VIS_S4)
+
+typedef struct mzs_vis_bn {
+    size_t w, b, mean, var;
+} mzs_vis_bn;
+typedef struct mzs_vis_res {
+    size_t conv_a, conv_b;
+    mzs_vis_bn bn;
+    int32_t C;
+} mzs_vis_res;
+typedef struct mzs_vis_mlp {
+    size_t in_w, in_b, mid_w, mid_b, out_w, out_b;
+    int32_t n_out;
+} mzs_vis_mlp;
+typedef struct mzs_vision_offsets {
+    size_t r_conv_in, r_conv_out, r_conv;
+    mzs_vis_res r_res_in, r_res_out, r_res;
+    mzs_vis_bn r_bn;
+    size_t d_conv, d_conv_rew, d_conv_rew_b;
+    mzs_vis_bn d_bn;
+    mzs_vis_res d_res;
+    mzs_vis_mlp d_fc;
+    mzs_vis_res p_res;
+    size_t p_conv_val, p_conv_val_b, p_conv_pol, p_conv_pol_b;
+    mzs_vis_mlp p_v, p_p;
+    size_t total;
+} mzs_vision_offsets;
+
+static inline size_t mzs_vis_bn_layout(mzs_vis_bn* b, size_t p, int C) {
+    b->w = p; p += (size_t)C;
+    b->b = p; p += (size_t)C;
+    b->mean = p; p += (size_t)C;
+    b->var = p; p += (size_t)C;
+    return p;
+}
+static inline size_t mzs_vis_res_layout(mzs_vis_res* r, size_t p, int C) {
+    r->C = C;
+    r->conv_a = p; p += (size_t)C * C * 9;
+    r->conv_b = p; p += (size_t)C * C * 9;
+    return mzs_vis_bn_layout(&r->bn, p, C);
+}
+static inline size_t mzs_vis_mlp_layout(mzs_vis_mlp* m, size_t p, int H, int L, int n_out) {
+    m->n_out = n_out;
+    m->in_w = p; p += (size_t)H * MZS_VIS_HIDDEN;
+    m->in_b = p; p += (size_t)H;
+    m->mid_w = p; p += L > 0 ? (size_t)H * H : 0;
+    m->mid_b = p; p += L > 0 ? (size_t)H : 0;
+    m->out_w = p; p += (size_t)n_out * H;
+    m->out_b = p; p += (size_t)n_out;
+    return p;
+}
+static inline mzs_vision_offsets mzs_vision_layout(const mzs_dims* d) {
+    mzs_vision_offsets o;
+    const int C = MZS_VIS_C, H = d->hidden_dim, L = d->n_mid_layers, Sd = d->state_dim, A = d->n_actions;
+    size_t p = 0;
+    o.r_conv_in = p; p += (size_t)(C / 2) * C * 9;
+    p = mzs_vis_res_layout(&o.r_res_in, p, C / 2);
+    o.r_conv_out = p; p += (size_t)C * (C / 2) * 9;
+    p = mzs_vis_res_layout(&o.r_res_out, p, C);
+    p = mzs_vis_res_layout(&o.r_res, p, C);
+    o.r_conv = p; p += (size_t)C * C * 9;
+    p = mzs_vis_bn_layout(&o.r_bn, p, C);
+    o.d_conv = p; p += (size_t)C * (C + 1) * 9;
+    p = mzs_vis_bn_layout(&o.d_bn, p, C);
+    p = mzs_vis_res_layout(&o.d_res, p, C);
+    o.d_conv_rew = p; p += (size_t)C * (C + 1);
+    o.d_conv_rew_b = p; p += (size_t)C;
+    p = mzs_vis_mlp_layout(&o.d_fc, p, H, L, Sd);
+    p = mzs_vis_res_layout(&o.p_res, p, C);
+    o.p_conv_val = p; p += (size_t)C * C;
+    o.p_conv_val_b = p; p += (size_t)C;
+    o.p_conv_pol = p; p += (size_t)C * C;
+    o.p_conv_pol_b = p; p += (size_t)C;
+    p = mzs_vis_mlp_layout(&o.p_v, p, H, L, Sd);
+    p = mzs_vis_mlp_layout(&o.p_p, p, H, L, A);
+    o.total = p;
+    return o;
+}
+
+/* floats in the weight blob of a model kind */
 static inline size_t mzs_blob_total(const mzs_dims* d) {
-    return d->model_kind == MZS_MODEL_LSTM ? mzs_lstm_layout(d).total : mzs_blob_layout(d).total;
+    return d->model_kind == MZS_MODEL_VISION ? mzs_vision_layout(d).total
+           : d->model_kind == MZS_MODEL_LSTM ? mzs_lstm_layout(d).total : mzs_blob_layout(d).total;
+}
+
+/* floats of one hidden state (the search's per-node state) */
+static inline int32_t mzs_hidden_floats(const mzs_dims* d) {
+    return d->model_kind == MZS_MODEL_VISION ? MZS_VIS_HIDDEN : d->state_dim;
 }
 
 static inline int32_t mzs_nodes_per_game(int32_t n_actions, int32_t num_simulations) {

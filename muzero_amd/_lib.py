@@ -37,7 +37,7 @@ class ArenaConfig(C.Structure):
 ARENA_LENGTH, ARENA_OBS, ARENA_ACTION, ARENA_REWARD, ARENA_ROOT_VALUE, ARENA_POLICY = 0, 1, 2, 3, 4, 5
 ARENA_ALIVE, ARENA_STATE, ARENA_STREAM_SEED, ARENA_SLOT_ROW, ARENA_QUEUE = 6, 7, 8, 9, 10
 ENV_CARTPOLE = 0
-MODEL_MLP, MODEL_LSTM = 0, 1
+MODEL_MLP, MODEL_LSTM, MODEL_VISION = 0, 1, 2
 PRECISION_F32, PRECISION_BF16 = 0, 1
 
 

@@ -80,11 +80,44 @@ def lstm_blob_layout(obs_dim, A, S_dim, H, L):
             head("d_st", S_dim + A, S_dim) + head("p_pol", S_dim, A) + head("p_val", S_dim, S_dim))
 
 
+VISION_SIDE, VISION_CHANNELS, VISION_HIDDEN_SIDE = 98, 3, 7      # muzero_model.py:312-314; 98 -> 49 -> 25 -> 13 -> 7
+VISION_HIDDEN = VISION_CHANNELS * VISION_HIDDEN_SIDE ** 2           # floats of one hidden state
+
+
+def vision_blob_layout(A, S_dim, H, L):
+    """'vision_model' blob (include/mzs_layout.h mzs_vision_layout): every DISTINCT tensor of
+    neural_network_vision_model.py's three modules once (its Sequentials repeat one Residual_block,
+    one BatchNorm2d and one Linear object in several places), BatchNorm running statistics included,
+    num_batches_tracked left out.  conv_a = the block's first and last 3x3 convolution
+    (`convolution_1`, :49-51, used at positions 3 and 11), conv_b the middle one (`convolution_3`)."""
+    C, hid = VISION_CHANNELS, VISION_HIDDEN
+
+    def bn(p, c):
+        return [(f"{p}_w", (c,)), (f"{p}_b", (c,)), (f"{p}_mean", (c,)), (f"{p}_var", (c,))]
+
+    def res(p, c):
+        return [(f"{p}_conv_a", (c, c, 3, 3)), (f"{p}_conv_b", (c, c, 3, 3))] + bn(f"{p}_bn", c)
+
+    def mlp(p, out):
+        mid = [(f"{p}_mid_w", (H, H)), (f"{p}_mid_b", (H,))] if L > 0 else []
+        return [(f"{p}_in_w", (H, hid)), (f"{p}_in_b", (H,))] + mid + [(f"{p}_out_w", (out, H)), (f"{p}_out_b", (out,))]
+
+    return ([("r_ds_conv_in", (C // 2, C, 3, 3))] + res("r_ds_res_in", C // 2) + [("r_ds_conv_out", (C, C // 2, 3, 3))] +
+            res("r_ds_res_out", C) + res("r_res", C) + [("r_conv", (C, C, 3, 3))] + bn("r_bn", C) +     # :141-142, unused path
+            [("d_conv", (C, C + 1, 3, 3))] + bn("d_bn", C) + res("d_res", C) +
+            [("d_conv_rew", (C, C + 1, 1, 1)), ("d_conv_rew_b", (C,))] + mlp("d_fc", S_dim) +
+            res("p_res", C) + [("p_conv_val", (C, C, 1, 1)), ("p_conv_val_b", (C,)),
+                               ("p_conv_pol", (C, C, 1, 1)), ("p_conv_pol_b", (C,))] +
+            mlp("p_v", S_dim) + mlp("p_p", A))
+
+
 def blob_layout(obs_dim, A, S_dim, H, L, kind=0, precision=0):
     """(name, shape) of every tensor in the packed blob, in order (include/mzs_layout.h).  The blob
     is fp32 whatever the compute precision (bf16 rounds a copy of it on the device)."""
     if kind == _lib.MODEL_LSTM:
         return lstm_blob_layout(obs_dim, A, S_dim, H, L)
+    if kind == _lib.MODEL_VISION:
+        return vision_blob_layout(A, S_dim, H, L)
     mid = lambda p: [(f"{p}_mid_w", (H, H)), (f"{p}_mid_b", (H,))] if L > 0 else []  # noqa: E731
     return ([("r_in_w", (H, obs_dim)), ("r_in_b", (H,))] + mid("r") +
             [("r_out_w", (S_dim, H)), ("r_out_b", (S_dim,))] +

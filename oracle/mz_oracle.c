@@ -80,6 +80,13 @@ static void softmax(const float* q, int n, float* p, float* scratch) {
     for (int i = 0; i < n; ++i) p[i] = mzs_div_r2(p[i], Z, rz); /* contract quotient (mzs_numeric.h) */
 }
 
+void mzo_softmax(const float* q, int32_t n, float* p) {
+    int P = mzs_pow2_ceil(n);
+    float* s = (float*)malloc(sizeof(float) * (size_t)P);
+    softmax(q, n, p, s);
+    free(s);
+}
+
 /* inverse_transform_with_support (muzero_model.py:571-587): softmax, expectation
  * over the support i - n/2, inverse value transform. */
 float mzo_support_to_scalar(const float* logits, int32_t n) {
@@ -233,6 +240,10 @@ static void pred_one(const mzs_dims* d, const float* blob, const mzs_blob_offset
 
 void mzo_representation(const mzs_dims* d, const float* blob, const float* obs, int32_t B,
                         float* hidden) {
+    if (d->model_kind == MZS_MODEL_VISION) {
+        mzo_vision_representation(d, blob, obs, B, hidden, NULL);
+        return;
+    }
     mzs_blob_offsets o = mzs_blob_layout(d);
     scratch s = scratch_new(d);
     g_bf16 = d->precision == MZS_PRECISION_BF16;
@@ -243,6 +254,10 @@ void mzo_representation(const mzs_dims* d, const float* blob, const float* obs, 
 
 void mzo_dynamics(const mzs_dims* d, const float* blob, const float* hidden,
                   const int32_t* action, int32_t B, float* reward, float* next_hidden) {
+    if (d->model_kind == MZS_MODEL_VISION) {
+        mzo_vision_dynamics(d, blob, hidden, action, B, reward, next_hidden, NULL);
+        return;
+    }
     mzs_blob_offsets o = mzs_blob_layout(d);
     scratch s = scratch_new(d);
     g_bf16 = d->precision == MZS_PRECISION_BF16;
@@ -254,6 +269,10 @@ void mzo_dynamics(const mzs_dims* d, const float* blob, const float* hidden,
 
 void mzo_prediction(const mzs_dims* d, const float* blob, const float* hidden, int32_t B,
                     float* policy, float* value) {
+    if (d->model_kind == MZS_MODEL_VISION) {
+        mzo_vision_prediction(d, blob, hidden, B, policy, value);
+        return;
+    }
     mzs_blob_offsets o = mzs_blob_layout(d);
     scratch s = scratch_new(d);
     g_bf16 = d->precision == MZS_PRECISION_BF16;

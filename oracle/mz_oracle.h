@@ -75,6 +75,17 @@ void mzo_dynamics(const mzs_dims* d, const float* blob, const float* hidden,
 void mzo_prediction(const mzs_dims* d, const float* blob, const float* hidden, int32_t B,
                     float* policy, float* value);
 
+/* 'vision_model' (oracle/mz_vision_oracle.c; pinned by tests/golden/model_L2_vis*.npz): obs
+ * [B][3][98][98], hidden states [B][3][7][7]; the three functions above dispatch here.  stages (may
+ * be NULL): Down_sample's output of the first observation; reward_logits (may be NULL) [B][S_dim]. */
+void mzo_vision_representation(const mzs_dims* d, const float* blob, const float* obs, int32_t B, float* hidden,
+                               float* stages);
+void mzo_vision_dynamics(const mzs_dims* d, const float* blob, const float* hidden, const int32_t* action, int32_t B,
+                         float* reward, float* next_hidden, float* reward_logits);
+void mzo_vision_prediction(const mzs_dims* d, const float* blob, const float* hidden, int32_t B, float* policy,
+                           float* value);
+void mzo_softmax(const float* q, int32_t n, float* p);
+
 /* building blocks exposed for unit pinning */
 void mzo_scale_to_bound(const float* x, int32_t n, float* y);
 float mzo_support_to_scalar(const float* logits, int32_t n);

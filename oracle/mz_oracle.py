@@ -93,10 +93,18 @@ def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
 
 
+VISION_HIDDEN = 3 * 7 * 7
+
+
+def hidden_floats(d):
+    """floats of one hidden state: S_dim, or the 3 x 7 x 7 feature map of the 'vision_model' (kind 2)"""
+    return VISION_HIDDEN if d.model_kind == 2 else d.state_dim
+
+
 def representation(d, blob, obs):
     obs = _f32(obs)
     B = obs.shape[0]
-    hid = np.empty((B, d.state_dim), np.float32)
+    hid = np.empty((B, hidden_floats(d)), np.float32)
     lib().mzo_representation(C.byref(d), _p(_f32(blob)), _p(obs), C.c_int32(B), _p(hid))
     return hid
 
@@ -106,7 +114,7 @@ def dynamics(d, blob, hidden, action):
     action = np.ascontiguousarray(action, dtype=np.int32)
     B = hidden.shape[0]
     rew = np.empty(B, np.float32)
-    nh = np.empty((B, d.state_dim), np.float32)
+    nh = np.empty((B, hidden_floats(d)), np.float32)
     lib().mzo_dynamics(C.byref(d), _p(_f32(blob)), _p(hidden), _p(action), C.c_int32(B), _p(rew), _p(nh))
     return rew, nh
 
