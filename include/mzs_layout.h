@@ -29,6 +29,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* the vision layout is also computed inside kernels */
+#if defined(__HIPCC__)
+#define MZS_LFN __host__ __device__ static inline
+#else
+#define MZS_LFN static inline
+#endif
+
 typedef struct mzs_dims {
     int32_t obs_dim;      /* flattened observation length                    */
     int32_t n_actions;    /* A                                               */
@@ -192,20 +199,20 @@ typedef struct mzs_vision_offsets {
     size_t total;
 } mzs_vision_offsets;
 
-static inline size_t mzs_vis_bn_layout(mzs_vis_bn* b, size_t p, int C) {
+MZS_LFN size_t mzs_vis_bn_layout(mzs_vis_bn* b, size_t p, int C) {
     b->w = p; p += (size_t)C;
     b->b = p; p += (size_t)C;
     b->mean = p; p += (size_t)C;
     b->var = p; p += (size_t)C;
     return p;
 }
-static inline size_t mzs_vis_res_layout(mzs_vis_res* r, size_t p, int C) {
+MZS_LFN size_t mzs_vis_res_layout(mzs_vis_res* r, size_t p, int C) {
     r->C = C;
     r->conv_a = p; p += (size_t)C * C * 9;
     r->conv_b = p; p += (size_t)C * C * 9;
     return mzs_vis_bn_layout(&r->bn, p, C);
 }
-static inline size_t mzs_vis_mlp_layout(mzs_vis_mlp* m, size_t p, int H, int L, int n_out) {
+MZS_LFN size_t mzs_vis_mlp_layout(mzs_vis_mlp* m, size_t p, int H, int L, int n_out) {
     m->n_out = n_out;
     m->in_w = p; p += (size_t)H * MZS_VIS_HIDDEN;
     m->in_b = p; p += (size_t)H;
@@ -215,7 +222,7 @@ static inline size_t mzs_vis_mlp_layout(mzs_vis_mlp* m, size_t p, int H, int L, 
     m->out_b = p; p += (size_t)n_out;
     return p;
 }
-static inline mzs_vision_offsets mzs_vision_layout(const mzs_dims* d) {
+MZS_LFN mzs_vision_offsets mzs_vision_layout(const mzs_dims* d) {
     mzs_vision_offsets o;
     const int C = MZS_VIS_C, H = d->hidden_dim, L = d->n_mid_layers, Sd = d->state_dim, A = d->n_actions;
     size_t p = 0;
@@ -250,7 +257,7 @@ static inline size_t mzs_blob_total(const mzs_dims* d) {
 }
 
 /* floats of one hidden state (the search's per-node state) */
-static inline int32_t mzs_hidden_floats(const mzs_dims* d) {
+MZS_LFN int32_t mzs_hidden_floats(const mzs_dims* d) {
     return d->model_kind == MZS_MODEL_VISION ? MZS_VIS_HIDDEN : d->state_dim;
 }
 

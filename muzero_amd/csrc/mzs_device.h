@@ -50,13 +50,15 @@ struct LstmHead {
 
 struct Model {
     int obs_dim, A, Sd, H, L;
-    int kind;       /* MZS_MODEL_MLP / MZS_MODEL_LSTM (include/mzs_layout.h)                 */
+    int kind;       /* MZS_MODEL_MLP / MZS_MODEL_LSTM / MZS_MODEL_VISION (include/mzs_layout.h) */
     int bf16;       /* 1: contract "dot_bf16" (include/mzs_numeric.h); w then holds bf16-rounded weights */
     int seg_state;  /* offset of the next-state segment in the dynamics heads (reward at 0) */
     int seg_value;  /* offset of the value segment in the prediction heads (policy at 0)     */
     Layer r_in, r_mid, r_out, d_in, d_mid, d_heads, p_in, p_mid, p_heads;
     LstmHead l_rew, l_st, l_pol, l_val; /* LSTM model only (r_in = its representation Linear) */
     const float* w; /* device weight store */
+    int hid;           /* floats of one hidden state: Sd, or 147 for the vision model */
+    const float* blob; /* master weights in blob order (what the vision model's functions read) */
 };
 
 /* 16-byte node record (replaces monte_carlo_tree_search.py:6-20 Node) */
@@ -353,9 +355,18 @@ __device__ __forceinline__ void seg_copy(const float* src, int n, float* dst, fl
     wave_sync();
 }
 
-/* Representation_function.forward: input in L.xh[0..obs), hidden state to L.xh and gdst */
-__device__ __forceinline__ void model_representation(const Model& m, const WaveLds& L,
+}  // namespace mzs
+#include "mzs_vision.h"
+namespace mzs {
+
+/* Representation_function.forward: input in L.xh[0..obs) (vision model: the image at obs_g, global),
+ * hidden state to L.xh and gdst */
+__device__ __forceinline__ void model_representation(const Model& m, const WaveLds& L, const float* obs_g,
                                                      float* gdst, int lane) {
+    if (m.kind == MZS_MODEL_VISION) {
+        vis_representation(m, L, obs_g, gdst, lane);
+        return;
+    }
     if (m.kind == MZS_MODEL_LSTM) { /* one Linear (neural_network_lstm_model.py:19-21) */
         wave_dense<false>(m.w, m.r_in, L.xh, L.ob, -1, lane, m.bf16);
         seg_copy(L.ob, m.Sd, L.xh, gdst, lane);
@@ -371,6 +382,7 @@ __device__ __forceinline__ void model_representation(const Model& m, const WaveL
  * state to L.xh and gdst */
 __device__ __forceinline__ float model_dynamics(const Model& m, const WaveLds& L, int action,
                                                 float* gdst, int lane) {
+    if (m.kind == MZS_MODEL_VISION) return vis_dynamics(m, L, action, gdst, lane);
     if (m.kind == MZS_MODEL_LSTM) {
         const float* r = lstm_head(m, m.l_rew, L, L.xh, m.Sd + action, lane);
         const float reward = seg_support_scalar(r, m.Sd, lane);
@@ -390,6 +402,7 @@ __device__ __forceinline__ float model_dynamics(const Model& m, const WaveLds& L
 /* Prediction_function.forward on L.xh: softmax policy as lane pairs, value (uniform) */
 __device__ __forceinline__ float model_prediction(const Model& m, const WaveLds& L, Pair* policy,
                                                   int lane) {
+    if (m.kind == MZS_MODEL_VISION) return vis_prediction(m, L, policy, lane);
     if (m.kind == MZS_MODEL_LSTM) {
         const float* pl = lstm_head(m, m.l_pol, L, L.xh, -1, lane);
         *policy = seg_softmax(seg_load(pl, m.A, lane));

@@ -160,9 +160,12 @@ __global__ void __launch_bounds__(256) k_search_fused(const SearchParams p) {
     if (kInjected) {
         pol = pair_from_global(p.t_root_policy + (size_t)g * A, A, lane);
     } else {
-        for (int k = lane; k < m.obs_dim; k += kWave) L.xh[k] = p.obs[(size_t)g * m.obs_dim + k];
+        /* vision model: the image stays in global memory (3 x 98 x 98 floats per game) */
+        const size_t obs_floats = m.kind == MZS_MODEL_VISION ? (size_t)MZS_VIS_C * m.obs_dim * m.obs_dim : (size_t)m.obs_dim;
+        if (m.kind != MZS_MODEL_VISION)
+            for (int k = lane; k < m.obs_dim; k += kWave) L.xh[k] = p.obs[(size_t)g * m.obs_dim + k];
         wave_sync();
-        model_representation(m, L, hid_g, lane);
+        model_representation(m, L, p.obs + (size_t)g * obs_floats, hid_g, lane);
         (void)model_prediction(m, L, &pol, lane);
     }
     wave_expand(c, L, 0, 0, 0.0f, pol, lane);
@@ -188,7 +191,7 @@ __global__ void __launch_bounds__(256) k_search_fused(const SearchParams p) {
             /* dynamics on the parent's hidden state, prediction on the new one (mcts.py:180-192) */
             const int e_parent = (pbase - 1) / A;
             const float* hp = hid_g + (size_t)e_parent * p.t.hid_stride;
-            for (int k = lane; k < m.Sd; k += kWave) L.xh[k] = hp[k];
+            for (int k = lane; k < m.hid; k += kWave) L.xh[k] = hp[k];
             wave_sync();
             reward = model_dynamics(m, L, action, hid_g + (size_t)e_new * p.t.hid_stride, lane);
             value = model_prediction(m, L, &pol, lane);
@@ -442,10 +445,10 @@ struct InferParams {
     Model m;
     LdsLayout lds;
     int batch;
-    const float* in;       /* obs [B][obs_dim] or hidden [B][Sd] */
+    const float* in;       /* obs [B][obs_dim] (vision: [B][3][98][98]) or hidden [B][hid] */
     const int* action;     /* [B]                                */
     float* reward;         /* [B]                                */
-    float* hidden_out;     /* [B][Sd]                            */
+    float* hidden_out;     /* [B][hid]                           */
     float* policy;         /* [B][A]                             */
     float* value;          /* [B]                                */
 };
@@ -461,17 +464,19 @@ __global__ void __launch_bounds__(256) k_inference(const InferParams p) {
     if (b >= p.batch) return;
     const WaveLds L = carve(smem + (size_t)wave * p.lds.bytes, p.lds);
     const Model& m = p.m;
-    const int n_in = kMode == kInferInitial ? m.obs_dim : m.Sd;
+    const bool vision = m.kind == MZS_MODEL_VISION;
+    const size_t obs_floats = vision ? (size_t)MZS_VIS_C * m.obs_dim * m.obs_dim : (size_t)m.obs_dim;
+    const int n_in = kMode == kInferInitial ? (vision ? 0 : m.obs_dim) : m.hid;
     for (int k = lane; k < n_in; k += kWave) L.xh[k] = p.in[(size_t)b * n_in + k];
     wave_sync();
     if (kMode == kInferInitial) {
-        model_representation(m, L, nullptr, lane);
+        model_representation(m, L, p.in + (size_t)b * obs_floats, nullptr, lane);
     } else if (kMode == kInferRecurrent) {
         const float reward = model_dynamics(m, L, p.action[b], nullptr, lane);
         if (lane == 0) p.reward[b] = reward;
     }
     if (kMode != kInferPrediction)
-        for (int k = lane; k < m.Sd; k += kWave) p.hidden_out[(size_t)b * m.Sd + k] = L.xh[k];
+        for (int k = lane; k < m.hid; k += kWave) p.hidden_out[(size_t)b * m.hid + k] = L.xh[k];
     if (p.policy || p.value) {
         Pair pol;
         const float value = model_prediction(m, L, &pol, lane);
@@ -817,6 +822,13 @@ void describe_model(const mzs_dims& d, Model* m, StoreBuilder* sb) {
     m->bf16 = d.precision == MZS_PRECISION_BF16;
     m->seg_state = round_up(Sd, 32);
     m->seg_value = Sd > 32 ? 64 : round_up(A, 32); /* wide heads: one 64-neuron group each (mzs_quadw.h) */
+    m->hid = mzs_hidden_floats(&d);
+    m->blob = nullptr;
+    if (d.model_kind == MZS_MODEL_VISION) { /* reads the blob itself: no transposed store */
+        const Layer none{0, 0, 0, 0};
+        m->r_in = m->r_mid = m->r_out = m->d_in = m->d_mid = m->d_heads = m->p_in = m->p_mid = m->p_heads = none;
+        return;
+    }
     if (d.model_kind == MZS_MODEL_LSTM) {
         const Layer none{0, 0, 0, 0};
         m->r_mid = m->r_out = m->d_in = m->d_mid = m->d_heads = m->p_in = m->p_mid = m->p_heads = none;
@@ -855,6 +867,11 @@ LdsLayout make_lds_layout(const Model& m, int n_nodes, int S) {
         const int out_pad = round_up(m.Sd > m.A ? m.Sd : m.A, 64);
         act = act > out_pad ? act : out_pad;
         ob = 3 * out_pad;
+    }
+    if (m.kind == MZS_MODEL_VISION) { /* mzs_vision.h: three maps of up to 49 x 49 floats, logits behind the third's head */
+        off = l.off_xh + kVisXh * 4;
+        act = kVisBuf > act ? kVisBuf : act;
+        ob = kVisBuf;
     }
     l.off_xa = off;
     off += act * 4;
@@ -1183,8 +1200,12 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     if (d.obs_dim < 1 || d.n_actions < 1 || d.state_dim < 1 || d.hidden_dim < 1 ||
         d.n_mid_layers < 0)
         return fail(MZS_E_ARG, "dims must be positive");
-    if (d.model_kind != MZS_MODEL_MLP && d.model_kind != MZS_MODEL_LSTM)
-        return fail(MZS_E_ARG, "model_kind must be MZS_MODEL_MLP or MZS_MODEL_LSTM");
+    if (d.model_kind != MZS_MODEL_MLP && d.model_kind != MZS_MODEL_LSTM && d.model_kind != MZS_MODEL_VISION)
+        return fail(MZS_E_ARG, "model_kind must be MZS_MODEL_MLP, MZS_MODEL_LSTM or MZS_MODEL_VISION");
+    if (d.model_kind == MZS_MODEL_VISION &&
+        (d.obs_dim != MZS_VIS_SIDE || d.n_mid_layers < 1 || d.precision != MZS_PRECISION_F32 || d.hidden_dim > 2048))
+        return fail(MZS_E_ARG, "vision_model: obs_dim = 98 (the image side, muzero_model.py:314), "
+                               "number_of_hidden_layer >= 1, fp32, hidden_layer_dimensions <= 2048");
     if (d.precision != MZS_PRECISION_F32 && d.precision != MZS_PRECISION_BF16)
         return fail(MZS_E_ARG, "precision must be MZS_PRECISION_F32 or MZS_PRECISION_BF16");
     if (d.model_kind == MZS_MODEL_LSTM && (d.n_mid_layers < 1 || d.n_mid_layers > MZS_LSTM_MAX_LAYERS))
@@ -1225,7 +1246,7 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     const size_t G = (size_t)cfg->max_games, Smax = (size_t)cfg->max_simulations;
     const int A = d.n_actions;
     h->tree.stride = round_up(h->n_nodes_max, 32);
-    h->tree.hid_stride = round_up(d.state_dim, 32);
+    h->tree.hid_stride = round_up(mzs_hidden_floats(&d), 32);
     h->tree.max_sims = cfg->max_simulations;
     int rc = MZS_OK;
     const size_t ts = (size_t)h->tree.stride;
@@ -1269,6 +1290,7 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
         return rc;
     }
     h->model.w = h->w_search_dev;
+    h->model.blob = h->blob_dev;
     h->stream_plan = make_stream_plan(d, h->model);
     if (h->stream_plan.n > 0 &&
         (rc = dev_alloc(h, &h->stream_dev, (size_t)h->stream_plan.n * kImageFloats))) {
@@ -1300,6 +1322,11 @@ int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats) {
     HIP_TRY(hipMemcpy(host.data(), blob, n_floats * sizeof(float), hipMemcpyDefault));
     const float* B = host.data();
     const int H = d.hidden_dim, Sd = d.state_dim, A = d.n_actions, ob = d.obs_dim;
+    if (d.model_kind == MZS_MODEL_VISION) { /* the kernels read the blob in place */
+        HIP_TRY(hipMemcpy(h->blob_dev, B, n_floats * sizeof(float), hipMemcpyHostToDevice));
+        h->have_weights = true;
+        return MZS_OK;
+    }
     StoreBuilder sb;
     Model m;
     describe_model(d, &m, &sb);
@@ -1853,6 +1880,8 @@ int mzs_train_create(mzs_handle* h, int32_t max_batch, int32_t unroll_steps) {
     if (d.state_dim > 64 || d.n_actions > 64)
         return fail(MZS_E_ARG, "training kernels hold one logit per lane: state_dim and n_actions <= 64");
     if (h->tape_dev) return fail(MZS_E_STATE, "mzs_train_create was already called on this handle");
+    if (d.model_kind == MZS_MODEL_VISION)
+        return fail(MZS_E_ARG, "training kernels exist for mlp_model and lstm_model (vision_model: inference and search)");
     HIP_TRY(hipSetDevice(h->cfg.device));
     if (d.model_kind == MZS_MODEL_LSTM) return lstm_train_create(h, max_batch, unroll_steps);
     const TapeLayout t = make_tape_layout(h->model, unroll_steps);

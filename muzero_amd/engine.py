@@ -45,6 +45,11 @@ class SearchEngine:
         self.obs_dim, self.A, self.S_dim, self.H, self.L = self.dims[:5]
         self.model_kind = self.dims[5] if len(self.dims) > 5 else _lib.MODEL_MLP
         self.precision = self.dims[6] if len(self.dims) > 6 else _lib.PRECISION_F32
+        vision = self.model_kind == _lib.MODEL_VISION
+        # one observation / one hidden state as the kernels see them: the vision model takes a
+        # (3, 98, 98) image and keeps a 3 x 7 x 7 feature map (147 floats) per node
+        self.obs_shape = (3, self.obs_dim, self.obs_dim) if vision else (self.obs_dim,)
+        self.hidden_floats = 147 if vision else self.S_dim
         self.max_games, self.max_simulations = int(max_games), int(max_simulations)
         self.discount = float(discount)
         self.frac = float(root_exploration_fraction)
@@ -107,7 +112,7 @@ class SearchEngine:
         dirichlet = self._dev(dirichlet, torch.float64)
         noise = self._dev(noise, torch.float64)
         G = obs.shape[0]
-        assert obs.shape == (G, self.obs_dim)
+        assert tuple(obs.shape) == (G,) + self.obs_shape
         stride = 0 if noise is None else noise.shape[1]
         if noise is not None:
             assert noise.shape[0] == G
@@ -179,7 +184,7 @@ class SearchEngine:
         seeds = self._dev(np.asarray(seeds, dtype=np.int64) if not isinstance(seeds, torch.Tensor) else seeds,
                           torch.int64)
         G, S = obs.shape[0], int(num_simulations)
-        assert obs.shape == (G, self.obs_dim) and seeds.shape == (G,)
+        assert tuple(obs.shape) == (G,) + self.obs_shape and seeds.shape == (G,)
         dirichlet, noise = self.stream_scratch(G, S)
         stride = noise.shape[1]
         self._keep = (obs, seeds)
@@ -292,7 +297,7 @@ class SearchEngine:
         for k in ("visit", "value_sum", "prior", "reward", "child_base"):
             t[k] = t[k][:, :n]
         t["sim_leaf"] = t["sim_leaf"][:, : self.num_simulations]
-        t["hidden"] = t["hidden"][:, : self.num_simulations + 1, : self.S_dim]
+        t["hidden"] = t["hidden"][:, : self.num_simulations + 1, : self.hidden_floats]
         return t
 
     def run_batch(self, observations, seeds=None, num_simulations=None, train=True,
@@ -314,7 +319,7 @@ class SearchEngine:
     def initial_inference(self, obs, want_prediction=True):
         obs = self._dev(obs, torch.float32)
         B = obs.shape[0]
-        hid = torch.empty((B, self.S_dim), dtype=torch.float32, device=self.device)
+        hid = torch.empty((B, self.hidden_floats), dtype=torch.float32, device=self.device)
         pol = torch.empty((B, self.A), dtype=torch.float32, device=self.device) if want_prediction else None
         val = torch.empty(B, dtype=torch.float32, device=self.device) if want_prediction else None
         _lib.check(self.lib.mzs_initial_inference(self.h, B, _ptr(obs), _ptr(hid), _ptr(pol),
@@ -326,7 +331,7 @@ class SearchEngine:
         action = self._dev(action, torch.int32)
         B = hidden.shape[0]
         rew = torch.empty(B, dtype=torch.float32, device=self.device)
-        nh = torch.empty((B, self.S_dim), dtype=torch.float32, device=self.device)
+        nh = torch.empty((B, self.hidden_floats), dtype=torch.float32, device=self.device)
         pol = torch.empty((B, self.A), dtype=torch.float32, device=self.device) if want_prediction else None
         val = torch.empty(B, dtype=torch.float32, device=self.device) if want_prediction else None
         _lib.check(self.lib.mzs_recurrent_inference(self.h, B, _ptr(hidden), _ptr(action), _ptr(rew),

@@ -1,0 +1,65 @@
+"""'vision_model' (ResNet-v2, neural_network_vision_model.py) on the GPU: the three inference entry
+points and a whole search through the C-ABI against the CPU oracle (bit for bit: same arithmetic
+contract, oracle/mz_vision_oracle.c) and against the reference's own outputs (1e-5)."""
+import numpy as np
+import pytest
+
+from conftest import fixture_weights, load_golden
+from test_vision_oracle import VISION_MODELS, close, value_close, vision_obs
+
+pytestmark = pytest.mark.gpu
+
+
+def engine_for(d, max_games, max_simulations=0, **kw):
+    from muzero_amd.engine import SearchEngine
+    return SearchEngine((d.obs_dim, d.n_actions, d.state_dim, d.hidden_dim, d.n_mid_layers, 2),
+                        max_games=max_games, max_simulations=max_simulations, **kw)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("name", VISION_MODELS)
+def test_vision_inference_equals_oracle_and_reference(name):
+    from oracle import mz_oracle as mzo
+    d, blob = fixture_weights(name)
+    fx = load_golden(f"model_L2_{name}.npz")
+    n = fx["hidden"].shape[0]
+    obs = vision_obs(fx, n)
+    eng = engine_for(d, n)
+    eng.set_weights(blob)
+    # initial inference: representation (Down_sample + residual block) + prediction
+    hid, pol, val = [t.cpu().numpy() for t in eng.initial_inference(obs)]
+    oh = mzo.representation(d, blob, obs)
+    op, ov = mzo.prediction(d, blob, oh)
+    assert np.array_equal(bits(hid), bits(oh))
+    assert np.array_equal(bits(pol), bits(op)) and np.array_equal(bits(val), bits(ov))
+    assert close(hid, fx["repr_hidden"].reshape(n, -1)) and close(pol, fx["ini_policy"])
+    assert value_close(val, fx["ini_value"])
+    # recurrent inference on the fixture's hidden states
+    h = fx["hidden"].reshape(n, -1)
+    rew, nh, pol, val = [t.cpu().numpy() for t in eng.recurrent_inference(h, fx["action"])]
+    orew, onh = mzo.dynamics(d, blob, h, fx["action"])
+    op, ov = mzo.prediction(d, blob, onh)
+    assert np.array_equal(bits(rew), bits(orew)) and np.array_equal(bits(nh), bits(onh))
+    assert np.array_equal(bits(pol), bits(op)) and np.array_equal(bits(val), bits(ov))
+    assert close(nh, fx["dyn_hidden"].reshape(n, -1)) and value_close(rew, fx["dyn_reward"])
+    assert close(pol, fx["rec_policy"]) and value_close(val, fx["rec_value"])
+    # prediction alone
+    pol, val = [t.cpu().numpy() for t in eng.prediction_inference(h)]
+    op, ov = mzo.prediction(d, blob, h)
+    assert np.array_equal(bits(pol), bits(op)) and np.array_equal(bits(val), bits(ov))
+    assert close(pol, fx["pred_policy"]) and value_close(val, fx["pred_value"])
+    eng.close()
+
+
+def test_vision_training_is_refused():
+    from muzero_amd import _lib
+    from muzero_amd.train import Trainer
+    d, blob = fixture_weights("visA")
+    eng = engine_for(d, 1)
+    eng.set_weights(blob)
+    with pytest.raises(_lib.MzsError):
+        Trainer(eng, 5, 16)
+    eng.close()
