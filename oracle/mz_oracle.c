@@ -177,6 +177,10 @@ static void lstm_head(const mzs_dims* d, const float* blob, const mzs_lstm_head_
 /* Representation_function.forward (neural_network_mlp_model.py:43-44) */
 static void repr_one(const mzs_dims* d, const float* blob, const mzs_blob_offsets* o,
                      const float* obs, float* hidden, scratch* s) {
+    if (d->model_kind == MZS_MODEL_VISION) { /* oracle/mz_vision_oracle.c */
+        mzo_vision_representation(d, blob, obs, 1, hidden, NULL);
+        return;
+    }
     if (d->model_kind == MZS_MODEL_LSTM) { /* one Linear, no activation, no rescaling (lstm:19-21) */
         const mzs_lstm_offsets lo = mzs_lstm_layout(d);
         dense(blob + lo.r_w, blob + lo.r_b, obs, d->state_dim, d->obs_dim, d->obs_dim, hidden);
@@ -196,6 +200,11 @@ static void dyn_one(const mzs_dims* d, const float* blob, const mzs_blob_offsets
                     const float* hidden, int action, float* reward, float* next_hidden,
                     scratch* s) {
     int H = d->hidden_dim, Sd = d->state_dim, ld = Sd + d->n_actions;
+    if (d->model_kind == MZS_MODEL_VISION) {
+        const int32_t a32 = action;
+        mzo_vision_dynamics(d, blob, hidden, &a32, 1, reward, next_hidden, NULL);
+        return;
+    }
     if (d->model_kind == MZS_MODEL_LSTM) {
         const mzs_lstm_offsets lo = mzs_lstm_layout(d);
         lstm_head(d, blob, &lo.rew, hidden, Sd, Sd + action, s->q, s);
@@ -221,6 +230,10 @@ static void dyn_one(const mzs_dims* d, const float* blob, const mzs_blob_offsets
 static void pred_one(const mzs_dims* d, const float* blob, const mzs_blob_offsets* o,
                      const float* hidden, float* policy, float* value, scratch* s) {
     int H = d->hidden_dim, Sd = d->state_dim, A = d->n_actions;
+    if (d->model_kind == MZS_MODEL_VISION) {
+        mzo_vision_prediction(d, blob, hidden, 1, policy, value);
+        return;
+    }
     if (d->model_kind == MZS_MODEL_LSTM) {
         const mzs_lstm_offsets lo = mzs_lstm_layout(d);
         lstm_head(d, blob, &lo.pol, hidden, Sd, -1, s->q, s);
@@ -301,7 +314,9 @@ static int search_one(const mzo_search_cfg* cfg, const float* blob, const mzs_bl
                       const double* noise, int64_t noise_cap, int g, tree* T, scratch* sc,
                       const mzo_search_out* out) {
     const mzs_dims* d = &cfg->dims;
-    const int A = d->n_actions, S = cfg->num_simulations, Sd = d->state_dim;
+    const int A = d->n_actions, S = cfg->num_simulations, Sd = mzs_hidden_floats(d); /* floats per hidden state */
+    const size_t obs_floats = d->model_kind == MZS_MODEL_VISION ? (size_t)MZS_VIS_C * d->obs_dim * d->obs_dim
+                                                                 : (size_t)d->obs_dim;
     const int N = mzs_nodes_per_game(A, S);
     const float g32 = (float)cfg->discount;               /* python float * np.float32 -> f32 */
     const float omf32 = (float)(1.0 - cfg->exploration_fraction);
@@ -322,7 +337,7 @@ static int search_one(const mzo_search_cfg* cfg, const float* blob, const mzs_bl
     if (tbl) {
         memcpy(pol, tbl->root_policy + (size_t)g * A, sizeof(float) * (size_t)A);
     } else {
-        repr_one(d, blob, bo, obs + (size_t)g * d->obs_dim, T->hidden, sc);
+        repr_one(d, blob, bo, obs + (size_t)g * obs_floats, T->hidden, sc);
         pred_one(d, blob, bo, T->hidden, pol, &value, sc);
     }
     T->child_base[0] = 1;
@@ -453,7 +468,7 @@ int mzo_search(const mzo_search_cfg* cfg, const float* blob, const mzo_table_mod
         T.prior = T.vsum + N;
         T.reward = T.prior + N;
         T.root_prior = (double*)malloc(sizeof(double) * (size_t)d->n_actions);
-        T.hidden = (float*)malloc(sizeof(float) * (size_t)(S + 1) * d->state_dim);
+        T.hidden = (float*)malloc(sizeof(float) * (size_t)(S + 1) * mzs_hidden_floats(d));
         scratch sc = scratch_new(d);
         g_bf16 = d->precision == MZS_PRECISION_BF16; /* threadprivate */
 #pragma omp for schedule(static)

@@ -182,7 +182,7 @@ def search(d, blob, S, gamma, frac, pbc_table, obs=None, dirichlet=None, noise=N
                   node_visit=((G, N), np.int32), node_vsum=((G, N), np.float32),
                   node_reward=((G, N), np.float32), node_prior=((G, N), np.float32),
                   child_base=((G, N), np.int32), minmax=((G, 2), np.float32),
-                  min_margin=((G,), np.float64), hidden=((G, S + 1, d.state_dim), np.float32))
+                  min_margin=((G,), np.float64), hidden=((G, S + 1, hidden_floats(d)), np.float32))
     res = {k: np.zeros(*shapes[k]) for k in want}
     out = SearchOut(*[(_p(res[k]).value if k in res else None) for k in _OUT_FIELDS])
     tbl = None

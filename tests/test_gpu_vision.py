@@ -54,6 +54,33 @@ def test_vision_inference_equals_oracle_and_reference(name):
     eng.close()
 
 
+@pytest.mark.parametrize("name,G,S", [("visA", 21, 30), ("visB", 9, 12)])
+def test_vision_search_equals_oracle(name, G, S):
+    """Whole searches (Monte_carlo_tree_search.run on the vision networks) through mzs_search_streams:
+    visit counts, root values, consumed draws and the hidden state of every expansion == the oracle's
+    search on the same images and streams, bit for bit.  One game per wavefront (k_search_fused)."""
+    from muzero_amd import rng
+    from oracle import mz_oracle as mzo
+    d, blob = fixture_weights(name)
+    obs = np.random.RandomState(7).uniform(0.0, 1.0, size=(G, 3, 98, 98)).astype(np.float32)
+    seeds = np.arange(G, dtype=np.int64) + 321
+    eng = engine_for(d, G, S, discount=0.997)
+    eng.set_weights(blob)
+    assert "fused" in eng.search_kernel_name(S)
+    eng.search_streams(obs, seeds, S, True)
+    out, tree = eng.results_host(), eng.tree_host()
+    dirichlet, noise = eng.fill_streams(seeds, S, True)
+    ref = mzo.search(d, blob, S, 0.997, 0.25, eng.pbc, obs=obs, dirichlet=dirichlet.cpu().numpy(),
+                     noise=noise.cpu().numpy(), train=True, want=("visits", "root_value", "consumed", "hidden"))
+    assert np.array_equal(out["visits"], ref["visits"])
+    assert np.array_equal(bits(out["root_value"]), bits(ref["root_value"]))
+    assert np.array_equal(out["consumed"], ref["consumed"])
+    assert np.array_equal(bits(tree["hidden"]), bits(ref["hidden"]))
+    assert out["visits"].sum() == G * S and np.all(tree["status"] == 0)
+    assert len({tuple(v) for v in out["visits"]}) > 1          # the searches are not all alike
+    eng.close()
+
+
 def test_vision_training_is_refused():
     from muzero_amd import _lib
     from muzero_amd.train import Trainer
