@@ -8,8 +8,9 @@ arguments (muzero_model.py:16-35), the attributes self_play.py / muzero_cli.py r
 `hidden_layer_dimension`, `number_of_hidden_layer`) and the three inference methods
 with their return types (muzero_model.py:828-905).
 
-`model_structure` "mlp_model" (neural_network_mlp_model.py) and "lstm_model"
-(neural_network_lstm_model.py) have kernels.  Weights live in one packed fp32 blob
+`model_structure` "mlp_model" (neural_network_mlp_model.py), "lstm_model"
+(neural_network_lstm_model.py) and "vision_model" (neural_network_vision_model.py, inference and
+search only) have kernels.  Weights live in one packed fp32 blob
 (include/mzs_layout.h).
 """
 import json
@@ -149,6 +150,43 @@ def blob_from_state_dicts(repr_sd, dyn_sd, pred_sd, L):
     return np.concatenate([p.ravel() for p in parts]).astype(np.float32)
 
 
+def vision_blob_from_state_dicts(repr_sd, dyn_sd, pred_sd, L):
+    """Pack the `state_dict()`s of the reference's three vision modules (neural_network_vision_model.py)
+    into vision_blob_layout order.  Their Sequentials repeat module objects, so a state_dict lists
+    one tensor under several keys: the first occurrence is taken."""
+    g = lambda sd, k: np.asarray(sd[k].detach().cpu().numpy() if hasattr(sd[k], "detach") else sd[k], np.float32)  # noqa: E731
+
+    def bn(sd, p):
+        return [g(sd, p + "weight"), g(sd, p + "bias"), g(sd, p + "running_mean"), g(sd, p + "running_var")]
+
+    def res(sd, p):          # Residual_block.sequential_container: 0 bn, 3 conv_1 (= conv_a), 7 conv_3 (= conv_b)
+        p += "sequential_container."
+        return [g(sd, p + "3.weight"), g(sd, p + "7.weight")] + bn(sd, p + "0.")
+
+    def mlp(sd, p):
+        last = 2 * L + 2
+        mid = [g(sd, p + "2.weight"), g(sd, p + "2.bias")] if L > 0 else []
+        return [g(sd, p + "0.weight"), g(sd, p + "0.bias")] + mid + [g(sd, p + f"{last}.weight"), g(sd, p + f"{last}.bias")]
+
+    if L < 1:
+        raise ValueError("vision_model: number_of_hidden_layer >= 1 (with 0 the dynamics and prediction "
+                         "Sequentials hold no residual block)")
+    ds = "sequential_downsampler.0.sequential_container."
+    parts = ([g(repr_sd, ds + "0.weight")] + res(repr_sd, ds + "1.") + [g(repr_sd, ds + "3.weight")] +
+             res(repr_sd, ds + "4.") + res(repr_sd, "sequential_downsampler.1.") +
+             [g(repr_sd, "sequential_convolution_activation.0.weight")] +
+             bn(repr_sd, "sequential_convolution_activation.1."))
+    parts += ([g(dyn_sd, "sequential_container.0.weight")] + bn(dyn_sd, "sequential_container.1.") +
+              res(dyn_sd, "sequential_container.3.") +
+              [g(dyn_sd, "sequential_reward.0.weight"), g(dyn_sd, "sequential_reward.0.bias")] +
+              mlp(dyn_sd, "sequential_reward.2."))
+    parts += (res(pred_sd, "resnet.0.") +
+              [g(pred_sd, "nn_value.0.weight"), g(pred_sd, "nn_value.0.bias"),
+               g(pred_sd, "nn_policy.0.weight"), g(pred_sd, "nn_policy.0.bias")] +
+              mlp(pred_sd, "nn_value.2.") + mlp(pred_sd, "nn_policy.2."))
+    return np.concatenate([p.ravel() for p in parts]).astype(np.float32)
+
+
 class Muzero:
     def __init__(self, model_structure="mlp_model", observation_space_dimensions=None,
                  action_space_dimensions=None, state_space_dimensions=9, k_hypothetical_steps=10,
@@ -168,9 +206,11 @@ class Muzero:
               device="cuda", num_of_epoch=300, hidden_layer_dimensions=64,
               number_of_hidden_layer=1, load=False, type_format=torch.float32, use_amp=False,
               scaler_on=False, bin_method="uniform_bin", bin_decomposition_number=10):
-        if model_structure not in (None, "mlp_model", "lstm_model"):
-            raise NotImplementedError(f"model_structure={model_structure!r}: 'mlp_model' and 'lstm_model' "
-                                      "have MI355X kernels (SURVEY.md §8f lists the others as next)")
+        if model_structure not in (None, "mlp_model", "lstm_model", "vision_model"):
+            raise NotImplementedError(f"model_structure={model_structure!r}: 'mlp_model', 'lstm_model' and "
+                                      "'vision_model' (inference and search) have MI355X kernels")
+        if model_structure == "vision_model" and (int(number_of_hidden_layer) < 1 or type_format is torch.bfloat16):
+            raise NotImplementedError("vision_model: number_of_hidden_layer >= 1, torch.float32")
         if model_structure == "lstm_model" and not 1 <= int(number_of_hidden_layer) <= 4:
             raise ValueError("lstm_model: number_of_hidden_layer is nn.LSTM's num_layers, 1..4 here")
         if type_format not in (torch.float32, torch.bfloat16, None):
@@ -197,14 +237,16 @@ class Muzero:
         self.random_tag = np.random.randint(0, 100000000)  # muzero_model.py:213 (global stream)
         self.store_loss = []
         self.bin_method, self.bin_decomposition_number = bin_method, bin_decomposition_number
-        self.is_RGB = False
+        self.is_RGB = "vision" in self.model_structure       # muzero_model.py:282
         self._engine = None
         self._trainer = None
         self._blob = None
         self._blob_stale = False
         self.weights_version = 0
         if not load:
-            self.observation_dimension = _space_size(observation_space_dimensions)
+            # vision models see a resized 98 x 98 RGB render whatever the environment (muzero_model.py:312-314)
+            self.observation_dimension = ((VISION_SIDE, VISION_SIDE, 3) if self.is_RGB
+                                          else _space_size(observation_space_dimensions))
             self.action_dictionnary = _action_dictionary(action_space_dimensions, bin_method,
                                                          bin_decomposition_number)
             self.action_dimension = len(self.action_dictionnary)
@@ -213,15 +255,31 @@ class Muzero:
     # ------------------------------------------------------------------ weights
     @property
     def dims(self):
-        d = (int(self.observation_dimension), int(self.action_dimension),
-             int(self.state_dimension), int(self.hidden_layer_dimension),
-             int(self.number_of_hidden_layer),
-             _lib.MODEL_LSTM if self.model_structure == "lstm_model" else _lib.MODEL_MLP)
+        kind = {"lstm_model": _lib.MODEL_LSTM, "vision_model": _lib.MODEL_VISION}.get(self.model_structure, _lib.MODEL_MLP)
+        obs = VISION_SIDE if self.is_RGB else int(self.observation_dimension)
+        d = (obs, int(self.action_dimension), int(self.state_dimension), int(self.hidden_layer_dimension),
+             int(self.number_of_hidden_layer), kind)
         return d + (self.precision,) if self.precision else d
 
     def initiate_model_weight(self):
         """weights_init (neural_network_mlp_model.py:287-292): N(0, 1/137.035999) for every
         Linear weight and bias, drawn from torch's global generator."""
+        if self.model_structure == "vision_model":
+            # muzero_model.py:326-331 skips weights_init for vision models: torch's own defaults stay —
+            # Conv2d / Linear kaiming_uniform(a = sqrt 5) = U(-1/sqrt(fan_in), 1/sqrt(fan_in)) for weight and
+            # bias, BatchNorm2d weight 1, bias 0, running_mean 0, running_var 1
+            parts, fan_in = [], 1
+            for name, shape in blob_layout(*self.dims):
+                if name.endswith(("_bn_w", "_var")):
+                    parts.append(torch.ones(shape).reshape(-1))
+                elif name.endswith(("_bn_b", "_mean")):
+                    parts.append(torch.zeros(shape).reshape(-1))
+                else:
+                    if len(shape) > 1:            # a bias follows its weight and shares its fan-in
+                        fan_in = int(np.prod(shape[1:]))
+                    parts.append((torch.rand(shape) * 2 - 1).reshape(-1) / np.sqrt(fan_in))
+            self.set_weights(torch.cat(parts).numpy())
+            return
         if self.model_structure == "lstm_model":
             # weights_init touches nn.Linear only; nn.LSTM keeps torch's own U(-1/sqrt(out), 1/sqrt(out))
             parts = []
@@ -274,6 +332,9 @@ class Muzero:
         return out
 
     def load_reference_state_dicts(self, repr_sd, dyn_sd, pred_sd):
+        if self.model_structure == "vision_model":
+            self.set_weights(vision_blob_from_state_dicts(repr_sd, dyn_sd, pred_sd, self.number_of_hidden_layer))
+            return
         if self.model_structure == "lstm_model":     # blob order == state_dict order
             g = lambda t: np.asarray(t.detach().cpu().numpy() if hasattr(t, "detach") else t, np.float32).ravel()  # noqa: E731
             self.set_weights(np.concatenate([g(t) for sd in (repr_sd, dyn_sd, pred_sd) for t in sd.values()]))
@@ -295,11 +356,25 @@ class Muzero:
             x = torch.as_tensor(np.asarray(x, dtype=np.float32))
         return x.reshape(1, -1) if x.dim() == 1 else x.reshape(x.shape[0], -1)
 
+    def _as_images(self, x):
+        """vision observations: (B, 3, 98, 98) float as game.py's transform makes them (:66-69)"""
+        x = x.detach().to(torch.float32) if torch.is_tensor(x) else torch.as_tensor(np.asarray(x, dtype=np.float32))
+        x = x[None] if x.dim() == 3 else x
+        if tuple(x.shape[1:]) != (3, VISION_SIDE, VISION_SIDE):
+            raise ValueError(f"vision_model observation {tuple(x.shape)}: expected (B, 3, 98, 98)")
+        return x.contiguous()
+
+    def _hidden_out(self, hid):
+        """hidden states as the reference returns them: (B, 3, 7, 7) maps for the vision model"""
+        hid = hid.cpu()
+        return hid.reshape(-1, VISION_CHANNELS, VISION_HIDDEN_SIDE, VISION_HIDDEN_SIDE) if self.is_RGB else hid
+
     def representation_function_inference(self, state):
-        """muzero_model.py:828-845: observation -> cpu Tensor (B, state_dimension)."""
-        hid, _, _ = self._inference_engine().initial_inference(self._as_batch(state),
-                                                               want_prediction=False)
-        return hid.cpu()
+        """muzero_model.py:828-845: observation -> cpu Tensor (B, state_dimension)
+        (vision model: (B, 3, 98, 98) -> (B, 3, 7, 7))."""
+        obs = self._as_images(state) if self.is_RGB else self._as_batch(state)
+        hid, _, _ = self._inference_engine().initial_inference(obs, want_prediction=False)
+        return self._hidden_out(hid)
 
     def dynamics_function_inference(self, state_normalized, action):
         """muzero_model.py:848-880: -> (np.float32 reward, cpu Tensor (1, state_dimension))."""
@@ -309,7 +384,7 @@ class Muzero:
             a = a.argmax(dim=1)
         a = a.reshape(-1).to(torch.int32)
         rew, nh, _, _ = self._inference_engine().recurrent_inference(h, a, want_prediction=False)
-        return rew.cpu().numpy()[0], nh.cpu()
+        return rew.cpu().numpy()[0], self._hidden_out(nh)
 
     def prediction_function_inference(self, state_normalized, reanalyze=False):
         """muzero_model.py:883-905: -> (np.ndarray (B, A) softmax policy, np.float32 value),
@@ -328,6 +403,10 @@ class Muzero:
         (neural_network_lstm_model.py:35), and so do the kernels: the order of the samples matters,
         and a rank's shard is a sequence of its own."""
         from . import train as tr
+        if self.model_structure == "vision_model":
+            raise NotImplementedError("train(): kernels exist for 'mlp_model' and 'lstm_model'; the vision model "
+                                      "runs inference and search (its training mode draws Dropout2d masks from "
+                                      "torch's generator and updates BatchNorm statistics: not built)")
         if self.loss_type != "general":
             raise NotImplementedError(f"loss_type={self.loss_type!r}: only the 'general' cross-entropy "
                                       "losses every shipped config uses (muzero_model.py:350-361)")

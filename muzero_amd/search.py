@@ -146,7 +146,10 @@ class Monte_carlo_tree_search:
         (RandomState(seed) per game: Dirichlet, then tie-break uniforms) unless
         `dirichlet` [G, A] / `noise` [G, >= mzs_max_draws] are given."""
         S = int(num_simulations)
-        obs = self._obs_batch(observations, model.dims[0])
+        if getattr(model, "is_RGB", False):          # vision model: (G, 3, 98, 98) images
+            obs = model._as_images(observations).numpy()
+        else:
+            obs = self._obs_batch(observations, model.dims[0])
         G, A = obs.shape[0], model.dims[1]
         noisy = bool(train) and S > 0
         eng = self._engine_for(model, G, S)

@@ -137,8 +137,13 @@ def main():
         for net in (mz.representation_function, mz.dynamics_function, mz.prediction_function):
             net.eval()
         blob = pack_vision(mz, L)
-        from muzero_amd.model import vision_blob_layout
+        from muzero_amd.model import vision_blob_from_state_dicts, vision_blob_layout
         assert blob.size == sum(int(np.prod(s)) for _, s in vision_blob_layout(A, Sd, H, L)), blob.size
+        # the drop-in's checkpoint mapping (Muzero.load_reference_state_dicts) against the module walk above
+        mapped = vision_blob_from_state_dicts(mz.representation_function.state_dict(),
+                                              mz.dynamics_function.state_dict(),
+                                              mz.prediction_function.state_dict(), L)
+        assert np.array_equal(mapped, blob), "vision_blob_from_state_dicts disagrees with pack_vision"
         mf.save(f"weights_{name}.npz", blob=blob, kind=np.int64(2), obs_dim=np.int64(98), A=np.int64(A),
                 S_dim=np.int64(Sd), H=np.int64(H), L=np.int64(L))
         mf.save(f"model_L2_{name}.npz", **vision_vectors(mz, A, 12, 900 + seed, 31 + seed))

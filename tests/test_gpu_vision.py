@@ -81,6 +81,37 @@ def test_vision_search_equals_oracle(name, G, S):
     eng.close()
 
 
+def test_vision_muzero_drop_in():
+    """Muzero(model_structure='vision_model'): the reference's wrapper surface (muzero_model.py:828-905)
+    — (1, 3, 98, 98) observations, (1, 3, 7, 7) hidden states — against the reference's own outputs, a
+    batched search through Monte_carlo_tree_search.run_batch, and train() refusing."""
+    import torch
+    from muzero_amd.model import Muzero
+    from muzero_amd.search import Monte_carlo_tree_search
+    d, blob = fixture_weights("visA")
+    fx = load_golden("model_L2_visA.npz")
+    mz = Muzero(model_structure="vision_model", observation_space_dimensions=(400, 600, 3),
+                action_space_dimensions=2, state_space_dimensions=31, hidden_layer_dimensions=64,
+                number_of_hidden_layer=1, k_hypothetical_steps=5)
+    assert mz.is_RGB and mz.observation_dimension == (98, 98, 3) and mz.dims == (98, 2, 31, 64, 1, 2)
+    fresh = mz.named_weights()                      # torch's default initialisation, not weights_init
+    assert np.all(fresh["r_res_bn_w"] == 1) and np.all(fresh["d_bn_var"] == 1) and np.all(fresh["p_res_bn_mean"] == 0)
+    assert np.abs(fresh["d_fc_in_w"]).max() <= 1 / np.sqrt(147) and np.abs(fresh["d_conv"]).max() <= 1 / 6
+    mz.set_weights(blob)
+    obs = vision_obs(fx, fx["hidden"].shape[0])
+    h0 = mz.representation_function_inference(torch.tensor(obs[:1]))
+    assert tuple(h0.shape) == (1, 3, 7, 7) and close(h0.numpy(), fx["repr_hidden"][:1])
+    pol, val = mz.prediction_function_inference(h0)
+    assert pol.shape == (1, 2) and close(pol, fx["ini_policy"][:1]) and value_close(val, fx["ini_value"][0])
+    rew, h1 = mz.dynamics_function_inference(torch.tensor(fx["hidden"][3:4]), int(fx["action"][3]))
+    assert tuple(h1.shape) == (1, 3, 7, 7) and close(h1.numpy(), fx["dyn_hidden"][3:4])
+    assert value_close(rew, fx["dyn_reward"][3])
+    res = Monte_carlo_tree_search(discount=0.997).run_batch(obs[:5], 10, mz, True, seeds=np.arange(5) + 3)
+    assert res.policy.shape == (5, 2) and np.all(res.policy.sum(axis=1) == 10)
+    with pytest.raises(NotImplementedError):
+        mz.train(None)
+
+
 def test_vision_training_is_refused():
     from muzero_amd import _lib
     from muzero_amd.train import Trainer
