@@ -302,6 +302,17 @@ int mzs_arena_play(mzs_arena* arena, mzs_handle* h, int32_t n_moves, int32_t num
                    double* dirichlet_dev, double* noise_dev, int64_t noise_stride, int32_t* alive_count_dev,
                    void* stream);
 
+/* What lock-step move `move` (0 = the first mzs_arena_step / move of mzs_arena_play after
+ * mzs_arena_begin) left behind: out6 = {move, next unplayed, queue end, done_upto (MZS_ARENA_QUEUE),
+ * slots with a running game, most draws any slot's search consumed (0 from mzs_arena_step, which is
+ * not told)}.  The move's last kernel stores the entry into pinned host memory, so this is a plain
+ * host read: no device call, no synchronisation, the stream keeps running.  It is the caller's
+ * business to know that the move has finished (an event recorded behind it): MZS_E_STATE if it has
+ * not, or if more than 256 later moves have overwritten the entry.  This is how the self-play loop
+ * of self_play.py:62 (`while not terminal and counter < limit`) is watched for thousands of games
+ * without draining the GPU's queue at every look. */
+int mzs_arena_status(mzs_arena* arena, int32_t move, int32_t* out6);
+
 /* ReplayBuffer.sample_batch's per-sample work (replay_buffer.py:147-151: make_image,
  * fill_gap_empty_action, Game.make_target game.py:237-260) for `batch` (row, position) pairs
  * chosen by the caller, written in the layout mzs_train_grad reads.  discount_pow_dev [td+1] =
@@ -317,6 +328,14 @@ int mzs_arena_make_batch(mzs_arena* arena, int32_t batch, const int32_t* row_pos
  * ReplayBuffer.save_game (replay_buffer.py:70-79) takes the per-game maximum of it. */
 int mzs_arena_priority(mzs_arena* arena, int32_t row0, int32_t n_rows, int32_t td_steps,
                        const double* discount_pow_dev, int32_t out_stride, double* priority_dev, void* stream);
+
+/* The same priorities without the zeros (Game.make_priority returns one array of game_length
+ * entries per game, game.py:262-284): game r's entries start at priority_dev[offsets_dev[r]],
+ * offsets_dev [n_rows] i64 = exclusive prefix sum of the rows' lengths (made by the caller, who
+ * sizes priority_dev from it), longest = the longest of those games. */
+int mzs_arena_priority_packed(mzs_arena* arena, int32_t row0, int32_t n_rows, int32_t td_steps,
+                              const double* discount_pow_dev, int32_t longest, const int64_t* offsets_dev,
+                              double* priority_dev, void* stream);
 
 #define MZS_ARENA_LENGTH 0     /* i32 [n_rows]                  game_length            */
 #define MZS_ARENA_OBS 1        /* f32 [n_rows][T][obs_dim]      observations            */

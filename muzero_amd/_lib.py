@@ -102,6 +102,9 @@ _SIGNATURES = {
                                        C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "mzs_arena_priority": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
                                      C.c_void_p, C.c_void_p]),
+    "mzs_arena_priority_packed": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                            C.c_void_p, C.c_void_p, C.c_void_p]),
+    "mzs_arena_status": (C.c_int, [C.c_void_p, C.c_int32, C.c_void_p]),
     "mzs_arena_array": (C.c_void_p, [C.c_void_p, C.c_int32]),
     "mzs_replay_sample_positions": (C.c_int, [C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                               C.c_void_p]),

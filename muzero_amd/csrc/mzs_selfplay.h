@@ -30,8 +30,11 @@ struct ArenaArrays {
     int* episode;           /* [G]    round counter (random-number key)                     */
     long long* stream_seed; /* [G]    RandomState seed of the slot's next search streams    */
     int* vrow;              /* [G]    virtual row of the slot's game (row = vrow % n_rows)   */
-    int* ctl;               /* [3]    VIRTUAL rows (they never wrap): next unplayed game, end of the queue,
-                                      and the row every game below which has finished         */
+    int* ctl;               /* [4]    VIRTUAL rows (they never wrap): next unplayed game, end of the queue,
+                                      and the row every game below which has finished; [3] = lock-step
+                                      moves since mzs_arena_begin                               */
+    int* status_ring;       /* [kArenaRing][8] pinned HOST memory: what move m left behind, written by the
+                                      move's last kernel: {m, ctl[0..2], alive slots, max draws consumed, m, 0} */
     /* per trajectory row (replaces the Game object's lists, game.py:46-55) */
     long long* row_seed;    /* [n_rows]          seed of the game recorded in the row       */
     int* row_episode;       /* [n_rows]          random-number key: the round the game was queued for */
@@ -43,6 +46,8 @@ struct ArenaArrays {
     float* root_value;      /* [n_rows][T]       root_values                                */
     float* policy;          /* [n_rows][T][A]    child_visits                               */
 };
+
+constexpr int kArenaRing = 256; /* moves whose status entries stay readable */
 
 /* seed of the (game, round, move) stream the search draws its Dirichlet noise and tie-break
  * uniforms from (mzs_fill_streams seeds a NumPy RandomState with it) */
@@ -93,6 +98,7 @@ __global__ void __launch_bounds__(256) k_arena_begin(const ArenaArrays a, int ro
         a.ctl[0] = row0 + started;
         a.ctl[1] = row0 + n_games;
         a.ctl[2] = row0; /* nothing has finished yet */
+        a.ctl[3] = 0;
     }
     for (int g = tid; g < a.G; g += nth) {
         if (g < n_games) {
@@ -112,11 +118,9 @@ __global__ void k_arena_enqueue(const ArenaArrays a, int n_games) {
 /* One move of every live game: store_search_statistics (game.py:154-168), policy_step
  * (game.py:176-225: temperature rescale, sample or argmax, env.step, append to the lists).
  * visits / root_value / root_prior are the search results of this move (mzs_results layout). */
-__global__ void __launch_bounds__(256) k_arena_step(const ArenaArrays a, const int* visits,
-                                                    const float* root_value, const double* root_prior,
-                                                    double temperature, int from_prior, float* obs_io) {
-    const int g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= a.G || !a.alive[g]) return;
+__device__ __forceinline__ void arena_step_slot(const ArenaArrays& a, int g, const int* visits,
+                                                const float* root_value, const double* root_prior,
+                                                double temperature, int from_prior, float* obs_io) {
     const int A = a.A, row = a.row[g], t = a.length[row];
     const int* v = visits + (size_t)g * A;
     /* store_search_statistics: visit fractions, or the normalised priors below 3 visits */
@@ -185,29 +189,51 @@ __global__ void __launch_bounds__(256) k_arena_step(const ArenaArrays a, const i
     a.stream_seed[g] = arena_stream_seed(a.seed[g], a.episode[g], t + 1);
 }
 
+__global__ void __launch_bounds__(256) k_arena_step(const ArenaArrays a, const int* visits,
+                                                    const float* root_value, const double* root_prior,
+                                                    double temperature, int from_prior, float* obs_io) {
+    const int g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= a.G || !a.alive[g]) return;
+    arena_step_slot(a, g, visits, root_value, root_prior, temperature, from_prior, obs_io);
+}
+
 /* Free slots take the round's next unplayed games, in slot order (deterministic: a block-wide
- * scan, no atomics); *alive_count = slots with a running game afterwards.  One block. */
+ * scan, no atomics); *alive_count = slots with a running game afterwards.  One block of
+ * kRefillThreads threads; thread t owns the consecutive slots [t * per, (t + 1) * per).  The move's
+ * status entry (see status_ring) is the last thing written.  consumed (may be null): draws each
+ * slot's search took (mzs_results), whose maximum the host sizes the next prefix from. */
 constexpr int kRefillThreads = 1024;
-__global__ void __launch_bounds__(kRefillThreads) k_arena_refill(const ArenaArrays a, float* obs_io,
-                                                                 int* alive_count) {
-    __shared__ int part[kRefillThreads];
-    const int tid = threadIdx.x;
+constexpr int kRefillWaves = kRefillThreads / 64;
+
+__device__ __forceinline__ void arena_refill_block(const ArenaArrays& a, float* obs_io, int* alive_count,
+                                                   const long long* consumed, int* wsum /* [2 * kRefillWaves] */) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int per = (a.G + kRefillThreads - 1) / kRefillThreads;
-    const int g0 = tid * per, g1 = g0 + per < a.G ? g0 + per : a.G;
+    const int g0 = tid * per < a.G ? tid * per : a.G, g1 = g0 + per < a.G ? g0 + per : a.G;
     const int next = a.ctl[0], end = a.ctl[1];
-    int dead = 0;
-    for (int g = g0; g < g1; ++g) dead += !a.alive[g];
-    part[tid] = dead;
-    __syncthreads();
-    for (int off = 1; off < kRefillThreads; off <<= 1) { /* inclusive Hillis-Steele scan */
-        const int v = tid >= off ? part[tid - off] : 0;
-        __syncthreads();
-        part[tid] += v;
-        __syncthreads();
+    int dead = 0, used = 0;
+    for (int g = g0; g < g1; ++g) {
+        dead += !a.alive[g];
+        if (consumed) used = consumed[g] > used ? (int)consumed[g] : used;
     }
-    int k = next + part[tid] - dead; /* virtual row of this thread's first free slot */
-    const int total_dead = part[kRefillThreads - 1];
-    int oldest = 0x7fffffff; /* oldest game still (or newly) running among this thread's slots */
+    /* inclusive scan of `dead` inside the wave, then over the sixteen wave totals */
+    int inc = dead;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int v = __shfl_up(inc, off, 64);
+        if (lane >= off) inc += v;
+    }
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    int base = 0, total_dead = 0;
+#pragma unroll
+    for (int i = 0; i < kRefillWaves; ++i) {
+        const int v = wsum[i];
+        base += i < w ? v : 0;
+        total_dead += v;
+    }
+    int k = next + base + inc - dead; /* virtual row of this thread's first free slot */
+    int oldest = 0x7fffffff;          /* oldest game still (or newly) running among this thread's slots */
     for (int g = g0; g < g1; ++g) {
         if (!a.alive[g]) {
             if (k < end) arena_start_game(a, g, k, obs_io);
@@ -215,19 +241,43 @@ __global__ void __launch_bounds__(kRefillThreads) k_arena_refill(const ArenaArra
         }
         if (a.alive[g]) oldest = a.vrow[g] < oldest ? a.vrow[g] : oldest;
     }
-    __syncthreads();
-    part[tid] = oldest;
-    __syncthreads();
-    for (int off = kRefillThreads / 2; off > 0; off >>= 1) {
-        if (tid < off) part[tid] = part[tid + off] < part[tid] ? part[tid + off] : part[tid];
-        __syncthreads();
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        const int v = __shfl_xor(oldest, off, 64), u = __shfl_xor(used, off, 64);
+        oldest = v < oldest ? v : oldest;
+        used = u > used ? u : used;
     }
+    __syncthreads(); /* every read of wsum's first half is done */
+    if (lane == 0) wsum[w] = oldest, wsum[kRefillWaves + w] = used;
+    __syncthreads();
     if (tid == 0) {
+        for (int i = 1; i < kRefillWaves; ++i) {
+            oldest = wsum[i] < oldest ? wsum[i] : oldest;
+            used = wsum[kRefillWaves + i] > used ? wsum[kRefillWaves + i] : used;
+        }
         const int started = next + total_dead <= end ? total_dead : end - next;
+        const int alive = a.G - total_dead + started;
+        const int done = oldest < next + started ? oldest : next + started;
+        const int move = a.ctl[3];
         a.ctl[0] = next + started;
-        a.ctl[2] = part[0] < next + started ? part[0] : next + started;
-        *alive_count = a.G - total_dead + started;
+        a.ctl[2] = done;
+        a.ctl[3] = move + 1;
+        *alive_count = alive;
+        if (a.status_ring) {
+            /* no fences: the reader's contract is to look only after an event behind this kernel
+             * has completed, when all of it is visible; the move index in both halves (two 16-byte
+             * stores) lets mzs_arena_status reject an entry it was asked for too early */
+            int4* e = reinterpret_cast<int4*>(a.status_ring + (size_t)(move % kArenaRing) * 8);
+            e[0] = make_int4(move, next + started, end, done);
+            e[1] = make_int4(alive, used, move, 0);
+        }
     }
+}
+
+__global__ void __launch_bounds__(kRefillThreads) k_arena_refill(const ArenaArrays a, float* obs_io,
+                                                                 int* alive_count, const long long* consumed) {
+    __shared__ int wsum[2 * kRefillWaves];
+    arena_refill_block(a, obs_io, alive_count, consumed, wsum);
 }
 
 struct BatchParams {
@@ -273,6 +323,20 @@ __global__ void __launch_bounds__(256) k_arena_priority(const ArenaArrays a, int
     if (pos < len && pos < a.T)
         v = fabs((double)a.root_value[(size_t)row * a.T + pos] - target_value(a, row, len, pos, td, disc_pow));
     out[i] = v;
+}
+
+/* the same, packed: game r's len(r) priorities at out[offsets[r] ...] (offsets = exclusive prefix sum
+ * of the rows' lengths, made by the caller) — what the host's ReplayStore keeps, without the zeros */
+__global__ void __launch_bounds__(256) k_arena_priority_packed(const ArenaArrays a, int row0, int n, int td,
+                                                               const double* disc_pow, int longest,
+                                                               const long long* offsets, double* out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * longest) return;
+    const int r = i / longest, pos = i - r * longest, row = row0 + r;
+    const int len = a.length[row];
+    if (pos < len && pos < a.T)
+        out[offsets[r] + pos] =
+            fabs((double)a.root_value[(size_t)row * a.T + pos] - target_value(a, row, len, pos, td, disc_pow));
 }
 
 /* ReplayBuffer.sample_batch's per-sample work (replay_buffer.py:147-151): make_image,

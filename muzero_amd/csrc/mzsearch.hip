@@ -2082,6 +2082,7 @@ struct mzs_arena {
     ArenaArrays a;
     long long queued_end = -1; /* host mirror of ctl[1] (virtual row behind the last queued game) */
     int* alive_count_dev = nullptr;
+    int* status_host = nullptr; /* [kArenaRing][8] pinned, coherent: the moves' status entries (ArenaArrays::status_ring) */
     std::vector<void*> allocs;
 };
 
@@ -2125,6 +2126,17 @@ int mzs_arena_create(const mzs_arena_config* cfg, mzs_arena** out) {
         mzs_arena_destroy(ar);
         return rc;
     }
+    void* ring = nullptr;
+    void* ring_dev = nullptr;
+    if (hipHostMalloc(&ring, sizeof(int) * 8 * kArenaRing, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(&ring_dev, ring, 0) != hipSuccess) {
+        if (ring) (void)hipHostFree(ring);
+        mzs_arena_destroy(ar);
+        return fail(MZS_E_HIP, "pinned host memory for the arena's status entries");
+    }
+    ar->status_host = static_cast<int*>(ring);
+    for (int i = 0; i < 8 * kArenaRing; ++i) ar->status_host[i] = -1;
+    a.status_ring = static_cast<int*>(ring_dev);
     *out = ar;
     return MZS_OK;
 }
@@ -2132,7 +2144,9 @@ int mzs_arena_create(const mzs_arena_config* cfg, mzs_arena** out) {
 void mzs_arena_destroy(mzs_arena* ar) {
     if (!ar) return;
     (void)hipSetDevice(ar->cfg.device);
+    (void)hipDeviceSynchronize(); /* no kernel may still write the status entries */
     for (void* p : ar->allocs) (void)hipFree(p);
+    if (ar->status_host) (void)hipHostFree(ar->status_host);
     delete ar;
 }
 
@@ -2171,25 +2185,34 @@ int mzs_arena_enqueue(mzs_arena* ar, int32_t n_games, const int64_t* seeds_dev, 
     return MZS_OK;
 }
 
+static int arena_step_launch(mzs_arena* ar, const int32_t* visits_dev, const float* root_value_dev,
+                             const double* root_prior_dev, const long long* used, double temperature,
+                             int32_t num_simulations, float* obs_dev, int32_t* alive_count_dev, hipStream_t st) {
+    const int from_prior = num_simulations < 1 ? 1 : 0;
+    /* two launches on purpose: one block stepping every slot before it refills them (a fused
+     * k_arena_move) was measured at 59 us per move against 8 + 9 us for this pair */
+    hipLaunchKernelGGL(k_arena_step, dim3((ar->a.G + 255) / 256), dim3(256), 0, st, ar->a, visits_dev, root_value_dev,
+                       root_prior_dev, temperature, from_prior, obs_dev);
+    hipLaunchKernelGGL(k_arena_refill, dim3(1), dim3(kRefillThreads), 0, st, ar->a, obs_dev, alive_count_dev, used);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
 int mzs_arena_step(mzs_arena* ar, const int32_t* visits_dev, const float* root_value_dev,
                    const double* root_prior_dev, double temperature, int32_t num_simulations, float* obs_dev,
                    int32_t* alive_count_dev, void* stream) {
     if (!ar || !visits_dev || !root_value_dev || !root_prior_dev || !obs_dev || !alive_count_dev)
         return fail(MZS_E_ARG, "null argument");
     HIP_TRY(hipSetDevice(ar->cfg.device));
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(k_arena_step, dim3((ar->a.G + 255) / 256), dim3(256), 0, st, ar->a, visits_dev,
-                       root_value_dev, root_prior_dev, temperature, num_simulations < 1 ? 1 : 0, obs_dev);
-    hipLaunchKernelGGL(k_arena_refill, dim3(1), dim3(kRefillThreads), 0, st, ar->a, obs_dev, alive_count_dev);
-    HIP_TRY(hipGetLastError());
-    return MZS_OK;
+    return arena_step_launch(ar, visits_dev, root_value_dev, root_prior_dev, nullptr, temperature, num_simulations,
+                             obs_dev, alive_count_dev, static_cast<hipStream_t>(stream));
 }
 
 int mzs_arena_play(mzs_arena* ar, mzs_handle* h, int32_t n_moves, int32_t num_simulations, int32_t train,
                    double alpha, double lo, double hi, int32_t prefix_draws, double temperature, float* obs_dev,
                    double* dirichlet_dev, double* noise_dev, int64_t noise_stride, int32_t* alive_count_dev,
                    void* stream) {
-    if (!ar || !h) return fail(MZS_E_ARG, "null argument");
+    if (!ar || !h || !obs_dev || !alive_count_dev) return fail(MZS_E_ARG, "null argument");
     if (n_moves < 0) return fail(MZS_E_ARG, "bad move count");
     if (ar->cfg.device != h->cfg.device) return fail(MZS_E_ARG, "arena and search handle live on different devices");
     if (ar->a.G > h->cfg.max_games) return fail(MZS_E_ARG, "the arena has more slots than the handle has games");
@@ -2198,10 +2221,22 @@ int mzs_arena_play(mzs_arena* ar, mzs_handle* h, int32_t n_moves, int32_t num_si
                                     reinterpret_cast<const int64_t*>(ar->a.stream_seed), alpha, lo, hi, prefix_draws,
                                     dirichlet_dev, noise_dev, noise_stride, stream);
         if (rc) return rc;
-        if ((rc = mzs_arena_step(ar, h->res.visits, h->res.root_value, h->res.root_prior, temperature, num_simulations,
-                                 obs_dev, alive_count_dev, stream)))
+        if ((rc = arena_step_launch(ar, h->res.visits, h->res.root_value, h->res.root_prior, h->res.consumed,
+                                    temperature, num_simulations, obs_dev, alive_count_dev,
+                                    static_cast<hipStream_t>(stream))))
             return rc;
     }
+    return MZS_OK;
+}
+
+int mzs_arena_status(mzs_arena* ar, int32_t move, int32_t* out6) {
+    if (!ar || !out6) return fail(MZS_E_ARG, "null argument");
+    if (move < 0) return fail(MZS_E_ARG, "bad move index");
+    const volatile int* e = ar->status_host + (size_t)(move % kArenaRing) * 8;
+    if (e[0] != move || e[6] != move)
+        return fail(MZS_E_STATE, "that move has not finished yet, or its entry has been overwritten");
+    for (int i = 0; i < 6; ++i) out6[i] = e[i];
+    if (e[0] != move || e[6] != move) return fail(MZS_E_STATE, "the entry was overwritten while it was read");
     return MZS_OK;
 }
 
@@ -2240,6 +2275,23 @@ int mzs_arena_priority(mzs_arena* ar, int32_t row0, int32_t n_rows, int32_t td_s
     hipLaunchKernelGGL(k_arena_priority, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), ar->a, row0, n_rows, td_steps, discount_pow_dev,
                        out_stride, priority_dev);
+    HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
+int mzs_arena_priority_packed(mzs_arena* ar, int32_t row0, int32_t n_rows, int32_t td_steps,
+                              const double* discount_pow_dev, int32_t longest, const int64_t* offsets_dev,
+                              double* priority_dev, void* stream) {
+    if (!ar || !discount_pow_dev || !priority_dev || !offsets_dev) return fail(MZS_E_ARG, "null argument");
+    if (row0 < 0 || n_rows < 0 || row0 + n_rows > ar->a.n_rows || td_steps < 0 || longest < 1)
+        return fail(MZS_E_ARG, "rows [row0, row0 + n_rows) out of range or bad sizes");
+    if (n_rows == 0) return MZS_OK;
+    HIP_TRY(hipSetDevice(ar->cfg.device));
+    const long long total = (long long)n_rows * longest;
+    if (total > 0x7fffffffLL) return fail(MZS_E_ARG, "n_rows * longest too large");
+    hipLaunchKernelGGL(k_arena_priority_packed, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), ar->a, row0, n_rows, td_steps, discount_pow_dev, longest,
+                       reinterpret_cast<const long long*>(offsets_dev), priority_dev);
     HIP_TRY(hipGetLastError());
     return MZS_OK;
 }

@@ -159,15 +159,17 @@ class SearchEngine:
             self._stream_scratch_key = key
         return self._stream_scratch
 
-    def adapt_stream_prefix(self):
-        """Host-side tuning of search_streams' prefix (a host sync: call it where the loop already
-        reads something back).  A redo pass costs a whole search however few games need it, so the
-        prefix should cover every game of a move almost always: 1.5 x the largest consumption of the
-        last search, in whole refreshes of the generator state (312 draws), never below the library
-        default.  Purely a speed knob: any prefix gives the same results."""
+    def adapt_stream_prefix(self, used=None):
+        """Host-side tuning of search_streams' prefix.  A redo pass costs a whole search however few
+        games need it, so the prefix should cover every game of a move almost always: 1.5 x the
+        largest consumption of the last search, in whole refreshes of the generator state (312
+        draws), never below the library default.  Purely a speed knob: any prefix gives the same
+        results.  used: that largest consumption if the caller already has it (Arena.status);
+        None reads it back from the device (a host sync: call it where the loop already waits)."""
         if self.n_games == 0 or self.num_simulations == 0:
             return self.stream_prefix
-        used = int(self.results()["consumed"][: self.n_games].max().item())
+        if used is None:
+            used = int(self.results()["consumed"][: self.n_games].max().item())
         want = -(-int(1.5 * used) // 312) * 312
         self.stream_prefix = max(want, 9 * self.A * self.num_simulations)
         return self.stream_prefix

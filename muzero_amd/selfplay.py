@@ -143,7 +143,8 @@ class ReplayStore:
 
         def __getitem__(self, g):
             s = self.s
-            return s._blocks[int(s._blk[g])][int(s._bidx[g]), : int(s._plen[g])]
+            blk, i, n = s._blocks[int(s._blk[g])], int(s._bidx[g]), int(s._plen[g])
+            return blk[i: i + n] if blk.ndim == 1 else blk[i, :n]     # packed block: i = the game's offset
 
         def __iter__(self):
             return (self[g] for g in range(len(self)))
@@ -155,8 +156,9 @@ class ReplayStore:
     def save_games(self, rows, lengths, root_values=None, rewards=None, priorities=None):
         """save_game (replay_buffer.py:59-84) for a block of finished games, in order, without a
         per-game Python loop.  priorities: [n, >= longest game] float64 from Arena.priority
-        (mzs_arena_priority), zero past each game's end; without it they are computed here from
-        [n, T] float32 host copies of root_values / rewards."""
+        (mzs_arena_priority), zero past each game's end, or the packed 1-d form of
+        Arena.priority_packed (game after game, sum(lengths) entries, no padding); without it they are
+        computed here from [n, T] float32 host copies of root_values / rewards."""
         rows = np.asarray(rows, np.int64).reshape(-1)
         lengths = np.asarray(lengths, np.int64).reshape(-1)
         m, n0 = len(rows), len(self.rows)
@@ -172,13 +174,20 @@ class ReplayStore:
             # appended whenever either mode is "priority" (replay_buffer.py:64-67, :70-79)
             pg = pops if self.game_sampling == "priority" else 0
             pp = pops if self.position_sampling == "priority" else 0
-            self.prio_game = np.concatenate([self.prio_game, prio.max(axis=1)])[pg:]
+            if prio.ndim == 1:          # packed: game i at [off[i], off[i] + lengths[i])
+                off = np.cumsum(lengths) - lengths
+                if prio.shape[0] != int(lengths.sum()):
+                    raise ValueError("packed priorities must hold sum(lengths) entries")
+                game_max, index, stride = np.maximum.reduceat(prio, off), off, prio.strides[0]
+            else:
+                game_max, index, stride = prio.max(axis=1), np.arange(m, dtype=np.int64), prio.strides[0]
+            self.prio_game = np.concatenate([self.prio_game, game_max])[pg:]
             bid, self._next_block = self._next_block, self._next_block + 1
             self._blocks[bid] = prio
             self._blk = np.concatenate([self._blk, np.full(m, bid, np.int64)])[pp:]
-            self._bidx = np.concatenate([self._bidx, np.arange(m, dtype=np.int64)])[pp:]
+            self._bidx = np.concatenate([self._bidx, index])[pp:]
             self._plen = np.concatenate([self._plen, lengths])[pp:]
-            self._addr = np.concatenate([self._addr, prio.ctypes.data + np.arange(m, dtype=np.int64) * prio.strides[0]])[pp:]
+            self._addr = np.concatenate([self._addr, prio.ctypes.data + index * stride])[pp:]
             for old in [k for k in self._blocks if len(self._blk) and k < int(self._blk[0])]:
                 del self._blocks[old]
             self.soft_prio_game = self.prio_game / np.sum(self.prio_game)
@@ -344,6 +353,7 @@ class Arena:
         if seeds.dim() != 1 or n < 1 or row0 < 0 or row0 + n > self.n_rows:
             raise ValueError(f"{n} games from row {row0} do not fit {self.n_rows} rows")
         self.seeds, self.episode, self.n_games = seeds, int(episode), n
+        self.moves_issued, self.pending = 0, []
         _lib.check(self.lib.mzs_arena_begin(self.h, int(row0), n, _ptr(seeds), int(episode), _ptr(self.obs),
                                             self.eng._stream()), "mzs_arena_begin")
         return self.obs
@@ -374,6 +384,22 @@ class Arena:
         _lib.check(self.lib.mzs_arena_step(self.h, _ptr(r["visits"]), _ptr(r["root_value"]),
                                            _ptr(r["root_prior"]), float(temperature), S, _ptr(self.obs),
                                            _ptr(self.alive_count), self.eng._stream()), "mzs_arena_step")
+        self.moves_issued += 1
+
+    def mark(self):
+        """An event behind the moves issued so far + the index of the last of them: once the event
+        has completed, status(index) is readable (no stream synchronisation, later moves keep running)."""
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(self.eng.device))
+        self.pending.append((ev, self.moves_issued - 1))
+        return self.pending[-1]
+
+    def status(self, move):
+        """mzs_arena_status: what lock-step move `move` left behind, read from pinned host memory:
+        dict(move, next, end, done_upto, alive, max_consumed)."""
+        out = (C.c_int32 * 6)()
+        _lib.check(self.lib.mzs_arena_status(self.h, int(move), out), "mzs_arena_status")
+        return dict(zip(("move", "next", "end", "done_upto", "alive", "max_consumed"), (int(v) for v in out)))
 
     def play(self, n_moves, num_simulations, temperature, train=True, lo=1e-7, hi=2e-7):
         """n_moves x (search with device-made streams, step) in one library call (mzs_arena_play):
@@ -385,6 +411,7 @@ class Arena:
                                            _ptr(dirichlet), _ptr(noise), noise.shape[1], _ptr(self.alive_count),
                                            e._stream()), "mzs_arena_play")
         e.n_games, e.num_simulations = self.G, S
+        self.moves_issued += int(n_moves)
 
     def priority(self, row0, n_rows, td_steps, discount, longest):
         """Game.make_priority for rows [row0, row0 + n_rows) on the device: float64 tensor
@@ -396,6 +423,21 @@ class Arena:
         self._keep_p = dp_d
         _lib.check(self.lib.mzs_arena_priority(self.h, int(row0), int(n_rows), int(td_steps), _ptr(dp_d), stride,
                                                _ptr(out), self.eng._stream()), "mzs_arena_priority")
+        return out
+
+    def priority_packed(self, row0, lengths_d, total, longest, td_steps, discount):
+        """Game.make_priority for rows [row0, row0 + len(lengths_d)) without the padding: one float64
+        device tensor of `total` = sum(lengths) entries, game after game (mzs_arena_priority_packed).
+        lengths_d: the rows' lengths on the device."""
+        dev = self.eng.device
+        dp_d = torch.as_tensor(discount_powers(discount, int(td_steps))).to(dev)
+        ln = lengths_d.to(torch.int64)
+        off = torch.cumsum(ln, 0) - ln
+        out = torch.empty(int(total), dtype=torch.float64, device=dev)
+        self._keep_p = (dp_d, off)
+        _lib.check(self.lib.mzs_arena_priority_packed(self.h, int(row0), int(ln.shape[0]), int(td_steps), _ptr(dp_d),
+                                                      max(1, int(longest)), _ptr(off), _ptr(out),
+                                                      self.eng._stream()), "mzs_arena_priority_packed")
         return out
 
     def make_batch(self, row_pos, num_unroll, td_steps, discount):
@@ -432,9 +474,13 @@ def play_round(engine, arena, seeds, episode, num_simulations, temperature, row0
     moves = 0
     while moves < arena.n_games * arena.T:
         arena.play(check_every, S, temperature, train)
+        ev, last = arena.mark()
+        arena.pending.pop()
         moves += check_every
-        engine.adapt_stream_prefix()
-        if int(arena.alive_count.item()) == 0:
+        ev.synchronize()
+        st = arena.status(last)
+        engine.adapt_stream_prefix(st["max_consumed"])
+        if st["alive"] == 0:
             break
     return moves
 
@@ -444,22 +490,37 @@ def play_moves(engine, arena, n_moves, num_simulations, temperature, train=True)
     arena.play(n_moves, num_simulations, temperature, train)
 
 
-def play_until(engine, arena, done_upto, num_simulations, temperature, check_every=16, train=True, max_moves=None):
+def play_until(engine, arena, done_upto, num_simulations, temperature, check_every=16, train=True, max_moves=None,
+               depth=2):
     """Lock-step moves until every game below virtual row `done_upto` has finished (rolling rounds:
     the slots those games free go to the queued games of the next round).  Returns the number of
-    lock-step moves and the queue state read at the end."""
+    lock-step moves examined, the status the last of them left (Arena.status) and the event behind it.
+
+    The GPU's queue is never drained to look: while games are still queued, `depth` chunks of
+    check_every moves are kept in flight and the host waits on the event behind the OLDEST chunk,
+    then reads that chunk's status entry from pinned memory.  When the round is seen complete, the
+    younger chunks are already running the next round's games (arena.pending keeps their events
+    for the next call).  In the final drain (queue empty) one chunk at a time is issued, so that no
+    search runs on an arena that has nothing left to play."""
     S = int(num_simulations)
-    obs = arena.obs
-    moves, q = 0, arena.queue_state()
+    moves, st, ev = 0, None, None
     limit = max_moves if max_moves is not None else (done_upto + arena.G) * arena.T
-    while q[2] < done_upto and moves < limit:
-        play_moves(engine, arena, check_every, S, temperature, train)
+    draining = False
+    while moves < limit:
+        while len(arena.pending) < (1 if draining else depth):
+            play_moves(engine, arena, check_every, S, temperature, train)
+            arena.mark()
+        ev, last = arena.pending.pop(0)
+        ev.synchronize()
+        st = arena.status(last)
         moves += check_every
-        engine.adapt_stream_prefix()
-        q = arena.queue_state()
-        if int(arena.alive_count.item()) == 0 and q[0] >= q[1]:
+        engine.adapt_stream_prefix(st["max_consumed"])
+        draining = st["next"] >= st["end"]
+        if st["done_upto"] >= done_upto:
+            break
+        if st["alive"] == 0 and draining:
             break                       # nothing running, nothing queued
-    return moves, q
+    return moves, st, ev
 
 
 def game_seed_index(rank, games_per_rank):
@@ -496,8 +557,7 @@ class SelfPlay:
         self.episode = 0
         self.rolling = bool(rolling)
         self.queued = 0                 # iterations whose games have been handed to the arena (rolling)
-        self.overlap_moves = 16         # lock-step moves queued before the host starts saving a round
-        self._carry, self._side = 0, None
+        self._side = None
         self.n_blocks = arena.n_rows // self.N
         need = -(-(store.window_size + 1) // self.N) + (2 if rolling else 1)
         if self.n_blocks < need:
@@ -589,24 +649,18 @@ class SelfPlay:
             if next_temperature is not None and self.queued == k + 1:
                 a.enqueue(seeds, k + 1, next_temperature)
                 self.queued += 1
-            moves, q = play_until(self.eng, a, (k + 1) * N, self.S, temperature)
-            self.lockstep_moves = moves + self._carry
-            self._carry = 0
-            # The host now saves this round (device->host copies, NumPy bookkeeping: ~10 ms for 32 768
-            # games).  Its rows are complete; the next round's games are already running — keep them
-            # running meanwhile: queue more moves on the main stream and read this round's rows on a
-            # side stream that only waits for the point where the round was seen complete.
+            # the step's temperature argument only reaches the games of the very first round
+            # (mzs_arena_begin); every queued game carries its own
+            moves, st, ev = play_until(self.eng, a, (k + 1) * N, self.S, temperature)
+            self.lockstep_moves = moves
+            # The host now saves this round (device->host copies, NumPy bookkeeping).  Its rows were
+            # complete when `ev` fired; the chunks play_until left in flight are already playing the
+            # next round's games on the main stream.  Read the rows on a side stream that waits for
+            # `ev` only, so that neither side waits for the other.
             dev = self.eng.device
-            main = torch.cuda.current_stream(dev)
-            done = torch.cuda.Event()
-            done.record(main)
-            if q[0] < q[1] or int(a.alive_count.item()) > 0:
-                play_moves(self.eng, a, self.overlap_moves, self.S,
-                           temperature if next_temperature is None else next_temperature)
-                self._carry = self.overlap_moves
             if self._side is None:
                 self._side = torch.cuda.Stream(dev)
-            self._side.wait_event(done)
+            self._side.wait_event(ev)
             with torch.cuda.stream(self._side):
                 out = self._save_round(row0)
             self._side.synchronize()
@@ -617,10 +671,16 @@ class SelfPlay:
         a, N = self.arena, self.N
         lengths_d = a.arrays["length"][row0:row0 + N]
         lengths = lengths_d.cpu().numpy()
-        longest = int(lengths.max())
+        longest, total = int(lengths.max()), int(lengths.sum())
         prio = None
         if self.store.uses_priority:
-            prio = a.priority(row0, N, self.store.td_steps, self.store.discount, longest).cpu().numpy()
+            # game after game without padding (a round of 32 768 CartPole games: 6 MB instead of the
+            # 75 MB of a [N, longest] table), into pinned memory the store then keeps
+            prio_d = a.priority_packed(row0, lengths_d, total, longest, self.store.td_steps, self.store.discount)
+            pinned = torch.empty(total, dtype=torch.float64, pin_memory=True)
+            pinned.copy_(prio_d, non_blocking=True)
+            torch.cuda.current_stream(self.eng.device).synchronize()
+            prio = pinned.numpy()
         self.store.save_games(np.arange(row0, row0 + N), lengths, priorities=prio)
         self.block = (self.block + 1) % self.n_blocks
         self.episode += 1

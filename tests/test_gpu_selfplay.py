@@ -68,6 +68,8 @@ def test_arena_step_vs_oracle(temperature):
         n_alive = orc.step(v, rv, pr, temperature)
         torch.cuda.synchronize()
         assert int(ar.alive_count.item()) == n_alive
+        st = ar.status(t)                                       # the move's entry in pinned host memory
+        assert (st["move"], st["alive"], st["max_consumed"]) == (t, n_alive, 0)
         assert np.array_equal(host(obs), orc.obs)
         assert np.array_equal(host(ar.arrays["alive"]), orc.alive)
         live = orc.alive == 1
@@ -117,6 +119,8 @@ def test_arena_rolling_queue_vs_oracle():
             full += n_alive == G
             assert int(ar.alive_count.item()) == n_alive
             assert ar.queue_state() == (*orc.queue, orc.done_upto)
+            st = ar.status(moves - 1)
+            assert (st["next"], st["end"], st["done_upto"], st["alive"]) == (*orc.queue, orc.done_upto, n_alive)
             live = orc.alive == 1
             assert np.array_equal(host(ar.arrays["alive"]), orc.alive)
             assert np.array_equal(host(ar.arrays["slot_row"])[live], orc.row[live])
@@ -131,6 +135,65 @@ def test_arena_rolling_queue_vs_oracle():
     assert orc.done_upto == 4 * N and n_alive == 0
     # the point of the queue: except for the last round's tail the slots were all busy
     assert full / moves > 0.7
+    ar.close(), eng.close()
+
+
+def test_large_arena_vs_oracle():
+    """More slots than the refill block has threads x 8: several slots per thread in the scan; same
+    oracle, same status entries."""
+    import torch
+    from muzero_amd.selfplay import Arena
+    from oracle import mz_oracle as mzo
+    G, T = 8300, 5
+    N = G + 700
+    eng, dims, _ = make_engine(G, 0)
+    ar = Arena(eng, G, N, T)
+    orc = mzo.ArenaOracle(G, T, n_rows=N)
+    seeds = np.arange(N, dtype=np.int64) * 31 + 2
+    obs = ar.begin(0, seeds, episode=1)
+    orc.begin(seeds, 1, row0=0)
+    rs = np.random.RandomState(4)
+    for t in range(3 * T):
+        (v, rv, pr), res = fake_results(rs, G, 2, eng.device)
+        ar.step(1.0, res, num_simulations=50)
+        n_alive = orc.step(v, rv, pr, 1.0)
+        torch.cuda.synchronize()
+        st = ar.status(t)
+        assert (st["next"], st["end"], st["done_upto"], st["alive"]) == (*orc.queue, orc.done_upto, n_alive)
+        assert np.array_equal(host(obs), orc.obs)
+        if n_alive == 0:
+            break
+    got = arena_host(ar)
+    assert n_alive == 0 and np.array_equal(got["length"], orc.length)
+    for k, w in (("obs", orc.traj_obs), ("action", orc.traj_action), ("policy", orc.traj_policy)):
+        assert np.array_equal(got[k], w), k
+    with pytest.raises(Exception):
+        ar.status(t + 1)                                        # a move that has not been played
+    ar.close(), eng.close()
+
+
+def test_priority_packed_equals_padded():
+    """mzs_arena_priority_packed == mzs_arena_priority without the zeros, bit for bit."""
+    import torch
+    from muzero_amd.selfplay import Arena
+    G, T, N = 96, 30, 250
+    eng, dims, _ = make_engine(G, 0)
+    ar = Arena(eng, G, N + 10, T)
+    ar.begin(10, np.arange(N, dtype=np.int64) * 17 + 3, episode=2)
+    rs = np.random.RandomState(9)
+    for t in range(N * T):
+        _, res = fake_results(rs, G, 2, eng.device)
+        ar.step(1.0, res, num_simulations=50)
+        if t % 8 == 7 and int(ar.alive_count.item()) == 0:
+            break
+    lengths_d = ar.arrays["length"][10:10 + N]
+    lengths = host(lengths_d)
+    for td in (3, 10):
+        padded = host(ar.priority(10, N, td, 0.997, int(lengths.max())))
+        packed = host(ar.priority_packed(10, lengths_d, int(lengths.sum()), int(lengths.max()), td, 0.997))
+        mask = np.arange(padded.shape[1])[None, :] < lengths[:, None]
+        assert packed.shape == (int(lengths.sum()),) and np.array_equal(packed, padded[mask])
+        assert np.all(padded[~mask] == 0)
     ar.close(), eng.close()
 
 

@@ -157,6 +157,40 @@ def test_save_games_block_equals_one_by_one():
     assert np.array_equal(a.soft_prio_game, b.soft_prio_game)
 
 
+@pytest.mark.parametrize("native", [False, True])
+def test_packed_priorities_equal_padded_table(native):
+    """save_games(priorities=<1-d packed array>) (what Arena.priority_packed delivers: game after game,
+    no padding) behaves as the [n, T] table does: same draws, ratios, prio_game and prio_position
+    through window overflow, sampling and update_value."""
+    rs = np.random.RandomState(21)
+    n, T, B, K = 700, 60, 32, 5
+    stores = [sp.ReplayStore(900, B, K, 10, native=native) for _ in range(2)]
+    for blk in range(3):                                  # three saves: the third overflows the window
+        lengths = rs.randint(1, T + 1, n)
+        prio = np.abs(rs.standard_normal((n, T))) * rs.choice([1e-3, 1.0, 50.0], (n, 1))
+        mask = np.arange(T)[None, :] < lengths[:, None]
+        prio[~mask] = 0.0
+        rows = np.arange(blk * n, (blk + 1) * n)
+        stores[0].save_games(rows, lengths, priorities=prio.copy())
+        stores[1].save_games(rows, lengths, priorities=prio[mask].copy())
+        with pytest.raises(ValueError):
+            sp.ReplayStore(900, B, K, 10).save_games(rows, lengths, priorities=prio[mask][:-1].copy())
+        for step in range(10):
+            outs = []
+            for st in stores:
+                np.random.seed(1000 * blk + step)
+                outs.append(st.sample_batch())
+            for a, b in zip(*outs):
+                assert np.array_equal(a, b)
+            newp = np.abs(np.random.RandomState(step).standard_normal((K, B))) * 3
+            for st in stores:
+                st.update_value(newp, outs[0][2])
+            assert np.array_equal(stores[0].prio_game, stores[1].prio_game)
+    assert len(stores[0]) == len(stores[1]) == 901
+    for a, b in zip(stores[0].prio_position, stores[1].prio_position):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("pos_mode", ["priority", "uniform"])
 def test_native_replay_loops_equal_numpy(pos_mode):
     """The library's host loops (mzs_replay.h: NumPy's pairwise sum / cumsum / searchsorted restated)
