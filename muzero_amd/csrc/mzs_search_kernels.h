@@ -104,7 +104,7 @@ __device__ __forceinline__ bool redo_skip_quad(const SearchParams& p, int g0) {
 }
 
 /* bf16 instantiations of k_search_quad (mzsearch_bf16.hip); nullptr: the shape has none */
-quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global);
+quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global, bool two_per_simd = false);
 
 /* ------------------------------------------------------------------------------
  * Quad fused engine (mzs_quad.h): four games per wavefront, dense layers on
@@ -265,8 +265,11 @@ __device__ __forceinline__ void quad_write_out(const SearchParams& p, const Quad
 
 /* kB16: contract "dot_bf16" (mzs_quad_bf16.h): packed bf16 weights in half the registers, dense
  * layers on v_mfma_f32_4x4x4_16B_bf16; the tree code and every epilogue are the fp32 ones */
-template <int SD, int NA, int H, bool kInjected, bool kMid = false, bool kHidG = false, bool kB16 = false>
-__global__ void __launch_bounds__(256, 1) k_search_quad(const SearchParams p, const QuadLayout ql) {
+/* kOcc: wavefronts per SIMD the register budget is compiled for.  2 (bf16 + kHidG only: packed weights
+ * take half the registers and the trees of sixteen games 50 KB of LDS) lets two blocks share a CU when
+ * a batch has more than sixteen games per CU: each wave's dependent chains hide behind the other's. */
+template <int SD, int NA, int H, bool kInjected, bool kMid = false, bool kHidG = false, bool kB16 = false, int kOcc = 1>
+__global__ void __launch_bounds__(256, kOcc) k_search_quad(const SearchParams p, const QuadLayout ql) {
     extern __shared__ __align__(16) unsigned char smem[];
     const QuadLane q = quad_lane();
     const int wave = threadIdx.x >> 6;

@@ -10,6 +10,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -1065,7 +1066,7 @@ struct SearchPlan {
     char name[96];
 };
 
-SearchPlan plan_search(const mzs_handle* h, int S) {
+SearchPlan plan_search(const mzs_handle* h, int S, int n_games) {
     SearchPlan pl;
     std::memset(&pl, 0, sizeof pl);
     const mzs_dims& d = h->cfg.dims;
@@ -1073,6 +1074,21 @@ SearchPlan plan_search(const mzs_handle* h, int S) {
     pl.kind = kPlanGeneric;
     std::snprintf(pl.name, sizeof pl.name, "k_search_fused<false>");
     if (h->cfg.engine != MZS_ENGINE_FUSED || mzs_max_draws(A, S) >= (1ll << 31)) return pl;
+    static const bool no_occ2 = std::getenv("MZS_NO_OCC2") != nullptr; /* measurement knob: same results either way */
+    if (d.precision == MZS_PRECISION_BF16 && (n_games + 15) / 16 > h->n_cus && !no_occ2) {
+        /* more blocks than CUs: the bf16 kernel compiled for two wavefronts per SIMD, two blocks per CU */
+        const QuadLayout qg = make_quad_layout(A, n_nodes, S, true, false);
+        quad_kernel_t k2 = mzs::pick_quad_kernel_bf16(d, true, true);
+        if (k2 && quad_waves_per_block(qg) == 4 && qg.shared_bytes + 4 * qg.wave_bytes <= kMaxLdsPerBlock / 2) {
+            pl.kind = kPlanQuad;
+            pl.kernel = k2;
+            pl.ql = qg;
+            pl.wpb = 4;
+            std::snprintf(pl.name, sizeof pl.name, "k_search_quad<%d,%d,%d,false,false,true,bf16,2 waves/SIMD>",
+                          d.state_dim, A, d.hidden_dim);
+            return pl;
+        }
+    }
     if (quad_kernel_t qk = pick_quad_kernel(d)) {
         /* sixteen games per CU with their hidden states in LDS if that fits; else the variant
          * with the hidden states in the global array, if it seats more waves per block */
@@ -1388,7 +1404,7 @@ static int search_launch(mzs_handle* h, int32_t n_games, int32_t S, int32_t trai
     p.noise_avail = noise_avail;
     p.overflow = h->overflow_dev;
     p.redo = redo;
-    const SearchPlan plan = plan_search(h, S);
+    const SearchPlan plan = plan_search(h, S, n_games);
     if (plan.kind == kPlanGeneric) return launch(k_search_fused<false>, p, n_games, p.lds, st);
     if (plan.kind == kPlanStream) {
         if (build_stream) {
@@ -1497,7 +1513,7 @@ int mzs_search_kernel_name(mzs_handle* h, int32_t num_simulations, char* name_ou
     if (!h || !name_out || name_size == 0) return fail(MZS_E_ARG, "null argument");
     if (num_simulations < 0 || num_simulations > h->cfg.max_simulations)
         return fail(MZS_E_ARG, "num_simulations exceeds max_simulations of the handle");
-    const SearchPlan plan = plan_search(h, num_simulations);
+    const SearchPlan plan = plan_search(h, num_simulations, h->cfg.max_games);
     std::snprintf(name_out, name_size, "%s", plan.name);
     return MZS_OK;
 }

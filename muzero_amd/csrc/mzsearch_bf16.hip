@@ -23,7 +23,18 @@ static quad_kernel_t pick_quad_kernel_b16_t(const mzs_dims& d) {
     }
     return nullptr;
 }
-quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global) {
+/* the same kernels compiled for two wavefronts per SIMD (hidden states in the global array, no tied
+ * mid layers: those need the whole register file) */
+static quad_kernel_t pick_quad_kernel_b16_occ2(const mzs_dims& d) {
+    if (d.obs_dim > 64 || d.model_kind != MZS_MODEL_MLP || d.n_mid_layers != 0) return nullptr;
+    if (d.state_dim == 31 && d.hidden_dim == 64) {
+        if (d.n_actions == 2) return k_search_quad<31, 2, 64, false, false, true, true, 2>;
+        if (d.n_actions == 4) return k_search_quad<31, 4, 64, false, false, true, true, 2>;
+    }
+    return nullptr;
+}
+quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global, bool two_per_simd) {
+    if (two_per_simd) return hid_global ? pick_quad_kernel_b16_occ2(d) : nullptr;
     return hid_global ? pick_quad_kernel_b16_t<true>(d) : pick_quad_kernel_b16_t<false>(d);
 }
 
