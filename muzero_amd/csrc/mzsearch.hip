@@ -979,6 +979,18 @@ quad_kernel_t pick_quad_kernel(const mzs_dims& d, bool hid_global = false) {
     return hid_global ? pick_quad_kernel_t<true>(d) : pick_quad_kernel_t<false>(d);
 }
 
+/* the kernels compiled for two wavefronts per SIMD (hidden states in the global array, no tied mid
+ * layers); fp32: ~35 register reloads from scratch per simulation, paid back by the second wave */
+quad_kernel_t pick_quad_kernel_occ2(const mzs_dims& d) {
+    if (d.precision == MZS_PRECISION_BF16) return mzs::pick_quad_kernel_bf16(d, true, true);
+    if (d.obs_dim > 64 || d.model_kind != MZS_MODEL_MLP || d.n_mid_layers != 0) return nullptr;
+    if (d.state_dim == 31 && d.hidden_dim == 64) {
+        if (d.n_actions == 2) return k_search_quad<31, 2, 64, false, false, true, false, 2>;
+        if (d.n_actions == 4) return k_search_quad<31, 4, 64, false, false, true, false, 2>;
+    }
+    return nullptr;
+}
+
 /* wide MLPs (mzs_quadw.h): the shape of experiments 127 / 128 */
 quad_kernel_t pick_quadw_kernel(const mzs_dims& d) {
     if (d.model_kind != MZS_MODEL_MLP || d.obs_dim > 64 || d.precision != MZS_PRECISION_F32) return nullptr;
@@ -1075,17 +1087,17 @@ SearchPlan plan_search(const mzs_handle* h, int S, int n_games) {
     std::snprintf(pl.name, sizeof pl.name, "k_search_fused<false>");
     if (h->cfg.engine != MZS_ENGINE_FUSED || mzs_max_draws(A, S) >= (1ll << 31)) return pl;
     static const bool no_occ2 = std::getenv("MZS_NO_OCC2") != nullptr; /* measurement knob: same results either way */
-    if (d.precision == MZS_PRECISION_BF16 && (n_games + 15) / 16 > h->n_cus && !no_occ2) {
-        /* more blocks than CUs: the bf16 kernel compiled for two wavefronts per SIMD, two blocks per CU */
+    if ((n_games + 15) / 16 > h->n_cus && !no_occ2) {
+        /* more blocks than CUs: the kernel compiled for two wavefronts per SIMD, two blocks per CU */
         const QuadLayout qg = make_quad_layout(A, n_nodes, S, true, false);
-        quad_kernel_t k2 = mzs::pick_quad_kernel_bf16(d, true, true);
+        quad_kernel_t k2 = pick_quad_kernel_occ2(d);
         if (k2 && quad_waves_per_block(qg) == 4 && qg.shared_bytes + 4 * qg.wave_bytes <= kMaxLdsPerBlock / 2) {
             pl.kind = kPlanQuad;
             pl.kernel = k2;
             pl.ql = qg;
             pl.wpb = 4;
-            std::snprintf(pl.name, sizeof pl.name, "k_search_quad<%d,%d,%d,false,false,true,bf16,2 waves/SIMD>",
-                          d.state_dim, A, d.hidden_dim);
+            std::snprintf(pl.name, sizeof pl.name, "k_search_quad<%d,%d,%d,false,false,true,%s2 waves/SIMD>",
+                          d.state_dim, A, d.hidden_dim, d.precision == MZS_PRECISION_BF16 ? "bf16," : "");
             return pl;
         }
     }

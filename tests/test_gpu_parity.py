@@ -248,6 +248,39 @@ def test_saturated_logits_bit_exact(shape):
         eng.close()
 
 
+
+@pytest.mark.parametrize("shape,S", [((4, 2, 31, 64, 0), 50), ((8, 4, 31, 64, 0), 24)])
+def test_two_waves_per_simd_kernel_vs_oracle(shape, S):
+    """More than sixteen games per CU (8192 + 37 games): mzs_search takes the kernel compiled for two
+    wavefronts per SIMD — two blocks share a CU, hidden states in the global array, a few dozen
+    register reloads from scratch per simulation.  Two launches in a row, == oracle bit for bit."""
+    from muzero_amd import rng
+    from muzero_amd.model import blob_layout
+    from oracle import mz_oracle as mzo
+    d = mzo.dims(*shape)
+    G, A = 8192 + 37, shape[1]
+    rs = np.random.RandomState(11 + S)
+    n_w = sum(int(np.prod(shp)) for _, shp in blob_layout(*shape))
+    blob = (rs.standard_normal(n_w) * 0.3).astype(np.float32)
+    obs = rs.uniform(-1, 1, size=(G, shape[0])).astype(np.float32)
+    dirichlet, noise = rng.noise_streams(np.arange(G) + 9, A, S, 0.25, True)
+    ref = mzo.search(d, blob, S, 0.997, 0.25, rng.pbc_table(S), obs=obs, dirichlet=dirichlet, noise=noise,
+                     train=True, n_threads=8, want=("visits", "root_value", "consumed", "node_vsum", "sim_leaf"))
+    eng = make_engine(d, G, S, 0.997)
+    eng.set_weights(blob)
+    assert eng.search_kernel_name(S).endswith(",2 waves/SIMD>"), eng.search_kernel_name(S)
+    for _ in range(2):
+        eng.search(obs, dirichlet, noise, S, True)
+        out, tree = eng.results_host(), eng.tree_host()
+        assert not tree["status"].any()
+        assert np.array_equal(out["visits"], ref["visits"])
+        assert same_bits(out["root_value"], ref["root_value"])
+        assert np.array_equal(out["consumed"], ref["consumed"])
+        assert np.array_equal(tree["sim_leaf"], ref["sim_leaf"])
+        assert same_bits(tree["value_sum"], ref["node_vsum"])
+    eng.close()
+
+
 @pytest.mark.parametrize("tag", ["tag123", "tag133", "tag127", "lstmA"])
 def test_full_size_4096_games_vs_oracle(tag):
     """BASELINE config C2: 4096 games x 50 simulations against the oracle on all games (bit-exact),

@@ -26,11 +26,12 @@ def main():
     ap.add_argument("--games-per-round", type=int, default=0, help="default 8 x --games")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--train-steps", type=int, default=50)
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"), help="precision of the model half of the search")
     ap.add_argument("--rolling", action="store_true",
                     help="queue the next round's games while the current one drains (SelfPlay(rolling=True))")
     a = ap.parse_args()
     G, S, T = a.games, a.sims, a.max_moves
-    dims = (4, 2, 31, 64, 0)
+    dims = (4, 2, 31, 64, 0, 0, 1 if a.dtype == "bf16" else 0)
     eng = SearchEngine(dims, max_games=G, max_simulations=S, discount=0.997)
     n = eng.weight_count()
     w0 = (np.random.RandomState(0).standard_normal(n) * 0.1).astype(np.float32)
@@ -83,7 +84,8 @@ def main():
     tot_moves = sum(o["game_moves"] for o in rr)
     tot_lock = sum(o["lockstep_moves"] for o in rr)
     tot_play = sum(o["play_s"] for o in rr)
-    print(json.dumps(dict(games_per_round=N, slots=G, sims=S, max_moves=T, batch=a.batch, rolling=a.rolling,
+    print(json.dumps(dict(games_per_round=N, slots=G, sims=S, max_moves=T, batch=a.batch, rolling=a.rolling, dtype=a.dtype,
+                          kernel=eng.search_kernel_name(S),
                           rounds_timed=len(rr), slot_utilisation=tot_moves / (tot_lock * G),
                           useful_sims_per_s=tot_moves * S / tot_play,
                           search_sims_per_s=tot_lock * G * S / tot_play,
