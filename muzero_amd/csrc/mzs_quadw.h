@@ -115,6 +115,22 @@ struct WideStream {
         }
         next_img = next_img + 1 == n_img ? 0 : next_img + 1;
     }
+    /* a quarter of load<I, KV>: four of the sixteen requests (k rows 16 part .. 16 part + 15); the
+     * fourth quarter moves on to the next image */
+    template <int I, int KV, int part>
+    __device__ __forceinline__ void load_part() {
+        typedef const __attribute__((address_space(1))) f32x4* P4;
+        P4 b = (P4)(img + (size_t)next_img * kImageFloats);
+        float(&wk)[64] = w[I % kBufs];
+#pragma unroll
+        for (int j = 4 * part; j < 4 * part + 4; ++j) {
+            if (4 * j < KV) {
+                const f32x4 v = b[j * 64];
+                wk[4 * j] = v[0], wk[4 * j + 1] = v[1], wk[4 * j + 2] = v[2], wk[4 * j + 3] = v[3];
+            }
+        }
+        if constexpr (part == 3) next_img = next_img + 1 == n_img ? 0 : next_img + 1;
+    }
     /* the stream starts at image `first` (KV0 rows used) in phase I */
     template <int I, int KV0>
     __device__ __forceinline__ void start(int first) {

@@ -23,6 +23,7 @@
 #include "mzs_quad.h"
 #include "mzs_search_kernels.h"
 #include "mzs_quadw.h"
+#include "mzs_quadw2.h"
 #include "mzs_quadl.h"
 #include "mzs_train.h"
 #include "mzs_train_lstm.h"
@@ -240,19 +241,21 @@ __device__ __forceinline__ const float* tab_copy(float*& cursor, const float* sr
 }
 
 /* ------------------------------------------------------------------------------
- * k_search_quadw: four games per wave for wide MLPs (mzs_quadw.h): weights streamed from the
- * store, hidden states in the global SoA array, trees in LDS.  Same search code as k_search_quad.
+ * k_search_quadw2: the wide-MLP search with the weight stream shared by pairs of waves
+ * (mzs_quadw2.h): each wave searches its own four games and computes one 64-neuron output group
+ * of every layer for the pair's eight.  One block = four waves = two pairs; every wave reaches
+ * every block barrier.
  * ---------------------------------------------------------------------------- */
 template <int SD, int NA, int H>
-__global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, const QuadLayout ql) {
+__global__ void __launch_bounds__(256, 1) k_search_quadw2(const SearchParams p, const QuadLayout ql) {
     extern __shared__ __align__(16) unsigned char smem[];
     const QuadLane q = quad_lane();
-    const int wave = threadIdx.x >> 6;
+    const int wave = threadIdx.x >> 6, pair = wave >> 1, u = wave & 1;
     const Model& m = p.m;
     const int S = p.S;
-    if (redo_skip_block(p, 4 * (blockDim.x >> 6))) return;
+    const int games_per_block = 4 * (blockDim.x >> 6); /* 16, or 8 when the trees of sixteen games do not fit */
+    if (redo_skip_block(p, games_per_block)) return;
 
-    /* block-shared tables: pb_c / reciprocals, and the small vectors of the simulation loop */
     quad_fill_tables(smem, ql, p);
     WideTabs T;
     {
@@ -268,34 +271,58 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
     }
     __syncthreads();
 
-    const int g0 = (blockIdx.x * (blockDim.x >> 6) + wave) * 4;
-    if (g0 >= p.n_games || redo_skip_quad(p, g0)) return;
+    /* games past n_games replay the last one and write nothing (whole waves included) */
+    const int gp0 = blockIdx.x * games_per_block + pair * 8, g0 = gp0 + 4 * u;
     const bool live = g0 + q.c < p.n_games;
     const int g = live ? g0 + q.c : p.n_games - 1;
     const QuadLds L = quad_carve(smem, ql, wave, q, false);
     WideBufs B;
     B.trunk = L.trunk;
     B.xin = L.trunk + 4 * kWideTrunk;
+    const PairBufs P = pair_carve(reinterpret_cast<float*>(smem + ql.shared_bytes) - (2 - pair) * kPairFloats);
     WideStream st;
-    st.init(p.img, p.n_img, q.lane);
+    const int n_half = p.n_img / 2;
+    st.init(p.img + (size_t)u * n_half * kImageFloats, n_half, q.lane);
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
     const int noise_cap = p.noise ? (int)p.noise_avail : 0;
-    float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * p.t.hid_stride;
+    const size_t game_hid = (size_t)(p.t.max_sims + 1) * p.t.hid_stride;
+    float* hid_g = p.t.hidden + (size_t)g * game_hid;
+    /* the global hidden rows of the pair's game rows 4 s + c (what wave 1 stores new states into) */
+    float* hid_s[2];
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+        const int gs = gp0 + 4 * s2 + q.c;
+        hid_s[s2] = p.t.hidden + (size_t)(gs < p.n_games ? gs : p.n_games - 1) * game_hid;
+    }
     float* xrow = B.xin + q.c * kWideX;
+    float* prow = P.xin + (4 * u + q.c) * kPairXStride;
 
     QuadState s = quad_state_init();
     quad_tree_init(L, q, p.n_nodes);
     double nz = S > 0 ? quad_noise_prefetch<NA>(s, q, noise, noise_cap) : 0.0;
 
-    /* root: representation -> prediction -> expand (mcts.py:88-123).  The weight stream starts at
-     * the prediction net (every net has an even number of chunks: phase 0) */
-    f32x4 pr;
+    /* root: representation (each wave for its own games, from the store's rows) -> prediction (shared) */
     for (int k = q.b; k < kWideX; k += 16) xrow[k] = k < m.obs_dim ? p.obs[(size_t)g * m.obs_dim + k] : 0.0f;
     wave_sync();
     wide_representation<SD, H>(m, B, q, hid_g);
-    st.template start<6 % kBufs, SD>(p.first_img);
-    (void)wide_prediction<SD, H, 6 % kBufs>(st, m, T, B, q, NA, &pr);
+    *reinterpret_cast<float4*>(prow + 4 * q.b) = *reinterpret_cast<const float4*>(xrow + 4 * q.b);
+    __syncthreads();
+    st.template start<1, SD>(p.first_img);
+    {
+        float* const none[2] = {nullptr, nullptr};
+#ifdef MZS_DIAG
+        unsigned long long d0[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        pair_model<SD, H, NA, true>(st, m, T, P, u, q, none, d0);
+#else
+        pair_model<SD, H, NA, true>(st, m, T, P, u, q, none);
+#endif
+    }
+    f32x4 pr;
+    {
+        const float4 v = *reinterpret_cast<const float4*>(P.pri + 4 * (4 * u + q.c));
+        pr = f32x4{v.x, v.y, v.z, v.w};
+    }
     quad_root_expand<NA>(L, s, q, p, g, pr);
 
 #ifdef MZS_DIAG
@@ -307,16 +334,25 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw(const SearchParams p, c
         wave_sync();
         const QuadSelect<NA> sel = quad_select<NA>(L, s, q, noise, noise_cap, sim);
         nz = quad_noise_prefetch<NA>(s, q, noise, noise_cap);
-        /* the parent's hidden state: 64 floats per game, four per lane */
         const int e_new = sim + 1, e_parent = (sel.pbase - 1) / NA;
         const float4 hv = *reinterpret_cast<const float4*>(hid_g + (size_t)e_parent * p.t.hid_stride + 4 * q.b);
-        *reinterpret_cast<float4*>(xrow + 4 * q.b) = hv;
-        wave_sync();
+        *reinterpret_cast<float4*>(prow + 4 * q.b) = hv;
+        if (q.b == 0) P.act[4 * u + q.c] = sel.action;
         DIAG_T(t1);
-        const float yr = wide_dynamics<SD, H, 0>(st, m, T, B, q, sel.action, hid_g + (size_t)e_new * p.t.hid_stride);
+        __syncthreads();
         DIAG_T(t2);
-        const float yv = wide_prediction<SD, H, 6 % kBufs>(st, m, T, B, q, NA, &pr);
+        float* const hdst[2] = {hid_s[0] + (size_t)e_new * p.t.hid_stride, hid_s[1] + (size_t)e_new * p.t.hid_stride};
+#ifdef MZS_DIAG
+        pair_model<SD, H, NA, false>(st, m, T, P, u, q, hdst, dsum);
+#else
+        pair_model<SD, H, NA, false>(st, m, T, P, u, q, hdst);
+#endif
         DIAG_T(t3);
+        const float yr = P.rew[4 * u + q.c], yv = P.val[4 * u + q.c];
+        {
+            const float4 v = *reinterpret_cast<const float4*>(P.pri + 4 * (4 * u + q.c));
+            pr = f32x4{v.x, v.y, v.z, v.w};
+        }
         float reward, value;
         halves_pair(quad_inverse_value_transform(q.half ? yv : yr), reward, value);
         quad_expand<NA>(L, q, sel, sim, pr, reward);
@@ -934,13 +970,13 @@ QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model, bool hid
 /* LDS plan of k_search_quadw / k_search_quadl: block-shared tables (incl. the small vectors of the
  * simulation loop), trunk [4][128] and xin [4][64] per wave, trees per game, no hidden states (they
  * live in the global SoA array) */
-QuadLayout make_quadw_layout(int n_nodes, int S, int tab_floats) {
+QuadLayout make_quadw_layout(int n_nodes, int S, int tab_floats, int pair_floats = 0) {
     QuadLayout l;
     l.off_inv64 = round_up((S + 2) * 8, 16);
     l.off_inv32 = 2 * l.off_inv64;
     l.off_onehot = l.off_inv32 + round_up((S + 2) * 4, 16);
     l.off_tabs = l.off_onehot;
-    l.shared_bytes = l.off_tabs + round_up(tab_floats * 4, 16);
+    l.shared_bytes = l.off_tabs + round_up(tab_floats * 4, 16) + 2 * pair_floats * 4; /* two pairs of waves per block */
     l.off_nwin = 4 * kWideTrunk * 4 + 4 * kWideX * 4;
     l.off_games = l.off_nwin + 64 * 8;
     int off = n_nodes * (int)sizeof(QNode);
@@ -995,7 +1031,7 @@ quad_kernel_t pick_quad_kernel_occ2(const mzs_dims& d) {
 quad_kernel_t pick_quadw_kernel(const mzs_dims& d) {
     if (d.model_kind != MZS_MODEL_MLP || d.obs_dim > 64 || d.precision != MZS_PRECISION_F32) return nullptr;
     if (d.state_dim == 61 && d.hidden_dim == 128 && d.n_actions == 2)
-        return k_search_quadw<61, 2, 128>;
+        return k_search_quadw2<61, 2, 128>;
     return nullptr;
 }
 
@@ -1018,14 +1054,19 @@ StreamPlan make_stream_plan(const mzs_dims& d, const Model& m) {
         for (int k0 = 0; k0 < K; k0 += 64) v.push_back(StreamUnit{ly.w_off + col, ly.n_pad, K, k0});
     };
     if (pick_quadw_kernel(d)) {
-        const auto net = [&](const Layer& in, const Layer& mid, const Layer& heads) {
-            unit(in, 0, m.Sd), unit(in, 64, m.Sd);
-            for (int l = 0; l < m.L; ++l) unit(mid, 0, m.H), unit(mid, 64, m.H);
-            unit(heads, 0, m.H), unit(heads, 64, m.H);
-        };
-        net(m.d_in, m.d_mid, m.d_heads);
-        pl.first = (int)v.size();
-        net(m.p_in, m.p_mid, m.p_heads);
+        /* k_search_quadw2: wave u of a pair consumes output group u of every layer — its images first
+         * for u = 0, then for u = 1; `first` = where the prediction net starts within a wave's half */
+        for (int u = 0; u < 2; ++u) {
+            const auto net = [&](const Layer& in, const Layer& mid, const Layer& heads) {
+                unit(in, 64 * u, m.Sd);
+                for (int l = 0; l < m.L; ++l) unit(mid, 64 * u, m.H);
+                unit(heads, 64 * u, m.H);
+            };
+            const int base = (int)v.size();
+            net(m.d_in, m.d_mid, m.d_heads);
+            pl.first = (int)v.size() - base;
+            net(m.p_in, m.p_mid, m.p_heads);
+        }
     } else if (pick_quadl_kernel(d)) {
         const auto head = [&](const LstmHead& hd) {
             unit(hd.lin, 0, m.Sd);
@@ -1126,14 +1167,15 @@ SearchPlan plan_search(const mzs_handle* h, int S, int n_games) {
     if (wide && h->stream_plan.n > 0) { /* n == 0: more chunks per simulation than kMaxImages */
         const int tab_floats = d.model_kind == MZS_MODEL_LSTM ? 4 * kLstmHeadTabFloats + 2 * A * 64
                                                               : kWideTabFloats + A * 128;
-        const QuadLayout ql = make_quadw_layout(n_nodes, S, tab_floats);
-        const int wpb = quad_waves_per_block(ql);
+        const QuadLayout ql = make_quadw_layout(n_nodes, S, tab_floats, lstm ? 0 : kPairFloats);
+        int wpb = quad_waves_per_block(ql);
+        if (!lstm) wpb &= ~1; /* k_search_quadw2 runs whole pairs of waves */
         if (wpb > 0) {
             pl.kind = kPlanStream;
             pl.kernel = wide;
             pl.ql = ql;
             pl.wpb = wpb;
-            std::snprintf(pl.name, sizeof pl.name, "k_search_quad%s<%d,%d,%d>", lstm ? "l" : "w", d.state_dim, A,
+            std::snprintf(pl.name, sizeof pl.name, "k_search_quad%s<%d,%d,%d>", lstm ? "l" : "w2", d.state_dim, A,
                           d.hidden_dim);
         }
     }

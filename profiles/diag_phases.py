@@ -31,6 +31,9 @@ v = np.array(list(out), dtype=np.float64)
 if tag == "tag123":
     v[3] -= v[2]   # k_search_quad stamps dynamics + prediction together in slot 3
 names = ["-", "select", "dynamics", "prediction", "expand+backup", "-", "-", "-"]
+if tag == "tag127":   # k_search_quadw2: slots 6 / 7 are parts of slot 3
+    names = ["    of the units: wait for weights / x rows", "select", "wait for the block (tree imbalance)", "dynamics + prediction", "expand+backup", "    of the units: matrix blocks",
+             "  of it: barrier waits", "  of it: dense units (x loads, requests, MFMAs)"]
 tot = v[1:5].sum()
 W = G / 4
 for n, x in zip(names, v):
