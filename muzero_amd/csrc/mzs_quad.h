@@ -182,8 +182,15 @@ struct __attribute__((aligned(16))) QNode {
 };
 
 /* per-wave LDS */
+/* LDS row strides (floats) chosen so that the sixteen 16-byte pieces one ds_read_b128 of the B operands
+ * fetches — rows of the four games x lane groups — fall into disjoint banks (64 banks of 4 bytes; with
+ * the natural strides 64 / 32 the four games' rows share theirs: a 4-way / 2-way conflict on the
+ * critical path of every layer).  Game records: see make_quad_layout. */
+constexpr int kTrunkStride = 68; /* trunk activations of a game */
+constexpr int kHidRowStride = 36; /* kHidG: the one hidden-state row per game */
+
 struct QuadLds {
-    float* trunk;            /* [4][64] trunk activations, game-major                      */
+    float* trunk;            /* [4][kTrunkStride] trunk activations, game-major            */
     double* nwin;            /* [64] tie-break draws of the next descent: [level][a][game]  */
     const float* onehot;     /* block-shared [NA][64] action columns of the dynamics input  */
     const double* pbc;       /* block-shared [S+2] sqrt(n) * pb_c(n)                        */
@@ -318,9 +325,9 @@ __device__ __forceinline__ void store4(float* p, const f32x4 v) {
 template <bool kPacked = true>
 __device__ __forceinline__ void quad_trunk_to_x(const QuadLds& L, const QuadLane& q, const f32x4 acc,
                                                 float (&x)[16]) {
-    store4(L.trunk + q.c * 64 + q.n0, elu4<kPacked>(acc));
+    store4(L.trunk + q.c * kTrunkStride + q.n0, elu4<kPacked>(acc));
     wave_sync();
-    quad_load_x(L.trunk + q.c * 64, q.grp, x);
+    quad_load_x(L.trunk + q.c * kTrunkStride, q.grp, x);
     wave_sync();
 }
 
@@ -467,7 +474,7 @@ __device__ __forceinline__ void quad_representation(const Model& m, const QuadLd
     };
     f32x4 acc = b4(m.r_in.b_off), odd = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
     for (int k = 0; k < m.obs_dim; ++k) {
-        const float wk = w[m.r_in.w_off + k * 64 + n], xk = L.trunk[q.c * 64 + k];
+        const float wk = w[m.r_in.w_off + k * 64 + n], xk = L.trunk[q.c * kTrunkStride + k];
         if (k & 1)
             odd = __builtin_amdgcn_mfma_f32_4x4x1f32(wk, xk, odd, 0, 0, 0);
         else

@@ -155,14 +155,17 @@ __device__ __forceinline__ f32x4 quad_dense_b(const s16x4 (&w)[NG], const s16x4 
 }
 
 /* ELU(trunk) of the four games -> LDS as bf16, back as the B operand of the next layer.  The
- * bf16 trunk rows share the memory of the fp32 kernel's trunk buffer ([4][64] halves). */
+ * bf16 trunk rows (64 halves each) share the memory of the fp32 kernel's trunk buffer, at offsets
+ * 64 c + 8 (c >> 1) halves: no uniform stride keeps the sixteen pieces of a ds_read_b128 (four games
+ * x four lane groups, 32 bytes apart) in disjoint banks, these offsets do. */
+__device__ __forceinline__ int quad_trunk_off_b(int c) { return 64 * c + 8 * (c >> 1); }
 template <bool kPacked = true>
 __device__ __forceinline__ void quad_trunk_to_xb(const QuadLds& L, const QuadLane& q, const f32x4 acc, s16x4 (&x)[4]) {
     const f32x4 t = elu4<kPacked>(acc);
     unsigned short* tr = reinterpret_cast<unsigned short*>(L.trunk);
-    *reinterpret_cast<uint2*>(tr + q.c * 64 + q.n0) = make_uint2(pack_bf16(t[0], t[1]), pack_bf16(t[2], t[3]));
+    *reinterpret_cast<uint2*>(tr + quad_trunk_off_b(q.c) + q.n0) = make_uint2(pack_bf16(t[0], t[1]), pack_bf16(t[2], t[3]));
     wave_sync();
-    quad_load_xb(tr + q.c * 64, q.grp, x);
+    quad_load_xb(tr + quad_trunk_off_b(q.c), q.grp, x);
     wave_sync();
 }
 
@@ -229,7 +232,7 @@ __device__ __forceinline__ void quad_representation_b(const Model& m, const Quad
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
     /* input layer: obs_dim <= 64 values per game, groups of four k, lane group g holds k 16g .. 16g+15 */
     s16x4 x[4];
-    quad_load_xb_f32(L.trunk + q.c * 64, q.grp, x);
+    quad_load_xb_f32(L.trunk + q.c * kTrunkStride, q.grp, x);
     wave_sync();
     f32x4 e = b4(m.r_in.b_off), o = zero;
     const int ng = (m.obs_dim + 3) / 4;

@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256, kOcc) k_search_quad(const SearchParams p,
      * to 6.5 KB of hidden states each (three or four actions, or more than ~55 simulations) */
     QuadLds L = quad_carve(smem, ql, wave, q, !kHidG);
     float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * p.t.hid_stride;
-    if constexpr (kHidG) L.hid = L.trunk + 4 * 64 + q.c * 32;
+    if constexpr (kHidG) L.hid = L.trunk + 4 * kTrunkStride + q.c * kHidRowStride;
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
     const int noise_cap = p.noise ? (int)p.noise_avail : 0;
@@ -316,9 +316,9 @@ __global__ void __launch_bounds__(256, kOcc) k_search_quad(const SearchParams p,
         for (int r = 0; r < 4; ++r) pr[r] = r < NA ? p.t_root_policy[(size_t)g * NA + r] : 0.0f;
     } else {
         if constexpr (kB16) { /* the bf16 input layer reads whole groups of four k: zero the row's tail */
-            for (int k = q.b; k < 64; k += 16) L.trunk[q.c * 64 + k] = k < m.obs_dim ? p.obs[(size_t)g * m.obs_dim + k] : 0.0f;
+            for (int k = q.b; k < 64; k += 16) L.trunk[q.c * kTrunkStride + k] = k < m.obs_dim ? p.obs[(size_t)g * m.obs_dim + k] : 0.0f;
         } else {
-            for (int k = q.b; k < m.obs_dim; k += 16) L.trunk[q.c * 64 + k] = p.obs[(size_t)g * m.obs_dim + k];
+            for (int k = q.b; k < m.obs_dim; k += 16) L.trunk[q.c * kTrunkStride + k] = p.obs[(size_t)g * m.obs_dim + k];
         }
         wave_sync();
         if constexpr (kB16)

@@ -951,7 +951,7 @@ QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model, bool hid
     l.off_onehot = l.off_inv32 + round_up((S + 2) * 4, 16);
     l.off_tabs = 0;
     l.shared_bytes = l.off_onehot + (with_model ? A * 64 * 4 : 0);
-    l.off_nwin = 4 * 64 * 4 + (with_model && !hid_lds ? 4 * 32 * 4 : 0); /* + one hidden-state row per game */
+    l.off_nwin = 4 * kTrunkStride * 4 + (with_model && !hid_lds ? 4 * kHidRowStride * 4 : 0); /* + one hidden-state row per game */
     l.off_games = l.off_nwin + 64 * 8;
     int off = n_nodes * (int)sizeof(QNode);
     l.g_vsum = off;
@@ -962,6 +962,10 @@ QuadLayout make_quad_layout(int A, int n_nodes, int S, bool with_model, bool hid
     off += with_model && hid_lds ? (S + 1) * 32 * 4 : 0;
     l.g_leafs = off;
     off += round_up((S + 1) * 2, 16);
+    /* game records 16 bytes past a multiple of 32: the hidden-state rows (128 bytes each) of the four
+     * games then sit 4 banks apart (mod 8), and a ds_read_b128 of the B operands — four games x two
+     * lane groups, whatever expansions the games read — touches disjoint banks */
+    while (off % 32 != 16) off += 16;
     l.g_bytes = off;
     l.wave_bytes = l.off_games + 4 * l.g_bytes;
     return l;
