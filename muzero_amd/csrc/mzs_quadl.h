@@ -79,7 +79,7 @@ __device__ __forceinline__ f32x4 lstm_head_quad(WideStream& st, const LstmHeadTa
 template <int SD>
 __device__ __forceinline__ void lstm_representation_quad(const Model& m, const WideBufs& Bf, const QuadLane& q,
                                                          float* hdst, int hid_stride) {
-    float* xrow = Bf.xin + q.c * kWideX;
+    float* xrow = Bf.xin + q.c * kWideXStride;
     const int n = quad_neuron_of_lane(q.lane);
     const float4 bv = *reinterpret_cast<const float4*>(m.w + m.r_in.b_off + q.n0);
     f32x4 e = f32x4{bv.x, bv.y, bv.z, bv.w}, o = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
@@ -105,8 +105,8 @@ __device__ __forceinline__ void lstm_representation_quad(const Model& m, const W
 template <int SD, int H>
 __device__ __forceinline__ float lstm_dynamics_quad(WideStream& st, const LstmTabs& T, const WideBufs& Bf,
                                                     const QuadLane& q, int action, float* hdst, int hid_stride) {
-    float* xrow = Bf.xin + q.c * kWideX;
-    float* trow = Bf.trunk + q.c * kWideTrunk;
+    float* xrow = Bf.xin + q.c * kWideXStride;
+    float* trow = Bf.trunk + q.c * kWideTStride;
     const WideValid vd = wide_valid(q, SD);
     const f32x4 hr = lstm_head_quad<SD, H, SD>(st, T.rew, xrow, action, trow, q);
     const float reward = wide_support_mean(wide_softmax<true>(hr, vd), vd, q, SD);
@@ -124,8 +124,8 @@ __device__ __forceinline__ float lstm_dynamics_quad(WideStream& st, const LstmTa
 template <int SD, int H>
 __device__ __forceinline__ float lstm_prediction_quad(WideStream& st, const LstmTabs& T, const WideBufs& Bf,
                                                       const QuadLane& q, int n_actions, f32x4* prior) {
-    float* xrow = Bf.xin + q.c * kWideX;
-    float* trow = Bf.trunk + q.c * kWideTrunk;
+    float* xrow = Bf.xin + q.c * kWideXStride;
+    float* trow = Bf.trunk + q.c * kWideTStride;
     const f32x4 hp = lstm_head_quad<SD, H, SD>(st, T.pol, xrow, -1, trow, q);
     *prior = wide_softmax<true>(hp, wide_valid(q, n_actions));
     const f32x4 hv = lstm_head_quad<SD, H, SD>(st, T.val, xrow, -1, trow, q);

@@ -31,10 +31,13 @@ namespace mzs {
 
 constexpr int kWideTrunk = 128; /* floats per game in the trunk buffer */
 constexpr int kWideX = 64;      /* floats per game in the input (hidden state / observation) buffer */
+/* row strides of those buffers: + 4 floats, so that the four games' rows of a ds_read_b128 of the B
+ * operands fall into disjoint LDS banks (mzs_quad.h kTrunkStride) */
+constexpr int kWideTStride = kWideTrunk + 4, kWideXStride = kWideX + 4;
 
 struct WideBufs {
-    float* xin;   /* [4][kWideX]     */
-    float* trunk; /* [4][kWideTrunk] */
+    float* xin;   /* [4][kWideXStride] */
+    float* trunk; /* [4][kWideTStride] */
 };
 
 __device__ __forceinline__ float game_sum(float v) {
@@ -221,6 +224,28 @@ __device__ __forceinline__ void wide_block(const float (&cur)[64], const float (
     __builtin_amdgcn_sched_barrier(0);
 }
 
+/* wide_block with the stream's next chunk (phase IN, KV rows) requested inside it */
+template <int K, int k0, int IN, int KV>
+__device__ __forceinline__ void wide_block_ld(WideStream& st, const float (&cur)[64], const float (&x)[16], f32x4& e,
+                                              f32x4& o) {
+    st.template load_part<IN, KV, 0>();
+    __builtin_amdgcn_sched_barrier(0);
+    wide_mfma16<K, k0, 0>(cur, x, e, o);
+    __builtin_amdgcn_sched_barrier(0);
+    st.template load_part<IN, KV, 1>();
+    __builtin_amdgcn_sched_barrier(0);
+    wide_mfma16<K, k0, 1>(cur, x, e, o);
+    __builtin_amdgcn_sched_barrier(0);
+    st.template load_part<IN, KV, 2>();
+    __builtin_amdgcn_sched_barrier(0);
+    wide_mfma16<K, k0, 2>(cur, x, e, o);
+    __builtin_amdgcn_sched_barrier(0);
+    st.template load_part<IN, KV, 3>();
+    __builtin_amdgcn_sched_barrier(0);
+    wide_mfma16<K, k0, 3>(cur, x, e, o);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
 /* one dense unit (one 64-neuron output group of a layer with fan-in K <= 128) on the stream: its
  * first chunk is in buffer I % kBufs; KVL = the rows needed of the chunk its last step requests (the
  * next unit's first) */
@@ -233,17 +258,11 @@ __device__ __forceinline__ f32x4 wide_unit(WideStream& st, const float* __restri
     float x[16], x2[16];
     quad_load_x(xrow, q.grp, x);
     if constexpr (K > 64) quad_load_x(xrow + 64, q.grp, x2);
-    /* the requests go out as one burst ahead of the block (scheduling barriers on both sides:
-     * a request issued between two MFMAs holds the matrix pipe for its whole issue time) */
+    /* the sixteen requests of the next chunk ride inside the matrix block, four ahead of each quarter */
+    static_assert(kAhead == 1, "chunk c + 1 is requested inside the matrix block of chunk c");
     __builtin_amdgcn_sched_barrier(0);
-    st.template load<I + kAhead, (K > 64 || kAhead > 1 ? 64 : KVL)>();
-    __builtin_amdgcn_sched_barrier(0);
-    wide_block<K, 0>(st.w[I % kBufs], x, e, o);
-    if constexpr (K > 64) {
-        st.template load<I + 1 + kAhead, (kAhead > 1 ? 64 : KVL)>();
-        __builtin_amdgcn_sched_barrier(0);
-        wide_block<K, 64>(st.w[(I + 1) % kBufs], x2, e, o);
-    }
+    wide_block_ld<K, 0, I + 1, (K > 64 ? 64 : KVL)>(st, st.w[I % kBufs], x, e, o);
+    if constexpr (K > 64) wide_block_ld<K, 64, I + 2, KVL>(st, st.w[(I + 1) % kBufs], x2, e, o);
     __builtin_amdgcn_sched_barrier(0);
     return e + o;
 }
@@ -333,8 +352,8 @@ __device__ __forceinline__ void wide_mid(const Model& m, const Layer ly, float* 
 template <int SD, int H>
 __device__ __forceinline__ void wide_representation(const Model& m, const WideBufs& B, const QuadLane& q, float* hdst) {
     constexpr int HP = (H + 63) / 64 * 64;
-    float* xrow = B.xin + q.c * kWideX;
-    float* trow = B.trunk + q.c * kWideTrunk;
+    float* xrow = B.xin + q.c * kWideXStride;
+    float* trow = B.trunk + q.c * kWideTStride;
     {
         constexpr int NG = HP / 64;
         f32x4 acc[NG];
@@ -373,8 +392,8 @@ template <int SD, int H, int I>
 __device__ __forceinline__ float wide_dynamics(WideStream& st, const Model& m, const WideTabs& T, const WideBufs& Bf,
                                                const QuadLane& q, int action, float* hdst) {
     static_assert(H > 64 && H <= 128 && SD <= 64, "two trunk groups, one chunk of state inputs");
-    float* xrow = Bf.xin + q.c * kWideX;
-    float* trow = Bf.trunk + q.c * kWideTrunk;
+    float* xrow = Bf.xin + q.c * kWideXStride;
+    float* trow = Bf.trunk + q.c * kWideTStride;
     wide_trunk_pf<SD, I>(st, T.d_in_b, T.d_onehot + action * 128, xrow, trow, q);
     for (int l = 0; l < m.L; ++l) wide_trunk_pf<H, I + 2>(st, T.d_mid_b, nullptr, trow, trow, q);
     const WideValid vd = wide_valid(q, SD);
@@ -395,8 +414,8 @@ __device__ __forceinline__ float wide_dynamics(WideStream& st, const Model& m, c
 template <int SD, int H, int I>
 __device__ __forceinline__ float wide_prediction(WideStream& st, const Model& m, const WideTabs& T, const WideBufs& Bf,
                                                  const QuadLane& q, int n_actions, f32x4* prior) {
-    float* xrow = Bf.xin + q.c * kWideX;
-    float* trow = Bf.trunk + q.c * kWideTrunk;
+    float* xrow = Bf.xin + q.c * kWideXStride;
+    float* trow = Bf.trunk + q.c * kWideTStride;
     wide_trunk_pf<SD, I>(st, T.p_in_b, nullptr, xrow, trow, q);
     for (int l = 0; l < m.L; ++l) wide_trunk_pf<H, I + 2>(st, T.p_mid_b, nullptr, trow, trow, q);
     const float* hb = T.p_heads_b + q.n0;

@@ -30,7 +30,7 @@ namespace mzs {
 
 /* row strides of the pair buffers: + 4 floats, so that the four game rows a ds_read_b128 of the B
  * operands touches (same columns, rows c = 0..3) fall into different LDS banks */
-constexpr int kPairXStride = kWideX + 4, kPairTStride = kWideTrunk + 4;
+constexpr int kPairXStride = kWideXStride, kPairTStride = kWideTStride;
 constexpr int kPairXin = 8 * kPairXStride;          /* floats */
 constexpr int kPairTrunk = 8 * kPairTStride;        /* floats, one of the two ping-pong buffers */
 constexpr int kPairXchg = 64;                       /* rew [8] | val [8] | act [8] | pad [8] | pri [8][4] */

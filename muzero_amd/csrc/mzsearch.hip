@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw2(const SearchParams p, 
     const QuadLds L = quad_carve(smem, ql, wave, q, false);
     WideBufs B;
     B.trunk = L.trunk;
-    B.xin = L.trunk + 4 * kWideTrunk;
+    B.xin = L.trunk + 4 * kWideTStride;
     const PairBufs P = pair_carve(reinterpret_cast<float*>(smem + ql.shared_bytes) - (2 - pair) * kPairFloats);
     WideStream st;
     const int n_half = p.n_img / 2;
@@ -295,7 +295,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw2(const SearchParams p, 
         const int gs = gp0 + 4 * s2 + q.c;
         hid_s[s2] = p.t.hidden + (size_t)(gs < p.n_games ? gs : p.n_games - 1) * game_hid;
     }
-    float* xrow = B.xin + q.c * kWideX;
+    float* xrow = B.xin + q.c * kWideXStride;
     float* prow = P.xin + (4 * u + q.c) * kPairXStride;
 
     QuadState s = quad_state_init();
@@ -407,14 +407,14 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
     const QuadLds L = quad_carve(smem, ql, wave, q, false);
     WideBufs B;
     B.trunk = L.trunk;
-    B.xin = L.trunk + 4 * kWideTrunk;
+    B.xin = L.trunk + 4 * kWideTStride;
     WideStream st;
     st.init(p.img, p.n_img, q.lane);
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
     const int noise_cap = p.noise ? (int)p.noise_avail : 0;
     float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * hs;
-    float* xrow = B.xin + q.c * kWideX;
+    float* xrow = B.xin + q.c * kWideXStride;
 
     QuadState s = quad_state_init();
     quad_tree_init(L, q, p.n_nodes);
@@ -981,7 +981,7 @@ QuadLayout make_quadw_layout(int n_nodes, int S, int tab_floats, int pair_floats
     l.off_onehot = l.off_inv32 + round_up((S + 2) * 4, 16);
     l.off_tabs = l.off_onehot;
     l.shared_bytes = l.off_tabs + round_up(tab_floats * 4, 16) + 2 * pair_floats * 4; /* two pairs of waves per block */
-    l.off_nwin = 4 * kWideTrunk * 4 + 4 * kWideX * 4;
+    l.off_nwin = 4 * kWideTStride * 4 + 4 * kWideXStride * 4;
     l.off_games = l.off_nwin + 64 * 8;
     int off = n_nodes * (int)sizeof(QNode);
     l.g_vsum = off;
