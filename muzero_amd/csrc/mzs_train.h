@@ -76,6 +76,19 @@ __device__ __forceinline__ void train_dense(const float* __restrict__ w, const L
         const float* __restrict__ wt = w + ly.w_off + j;
         float e = w[ly.b_off + j], o = 0.0f;
         int k = 0;
+        /* sixteen weight rows requested before the first fma that needs one: the chains are short and
+         * the wave is alone on its SIMD, so the loop is bound by load latency, not by issue (same
+         * chains, same order: even k into e, odd k into o) */
+        for (; k + 15 < kdim; k += 16) {
+            float wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = wt[(size_t)(k + u) * ly.n_pad];
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) {
+                e = mzs_fma(wv[u], x[k + u], e);
+                o = mzs_fma(wv[u + 1], x[k + u + 1], o);
+            }
+        }
         for (; k + 1 < kdim; k += 2) {
             e = mzs_fma(wt[(size_t)k * ly.n_pad], x[k], e);
             o = mzs_fma(wt[(size_t)(k + 1) * ly.n_pad], x[k + 1], o);
@@ -96,6 +109,16 @@ __device__ __forceinline__ void train_back_input(const float* __restrict__ W, in
         if (k < nin) {
             float e = accumulate ? gx[k] : 0.0f, o = 0.0f;
             int j = 0;
+            for (; j + 15 < nout; j += 16) { /* as train_dense: sixteen rows in flight */
+                float wv[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) wv[u] = W[(size_t)(j + u) * ld + k];
+#pragma unroll
+                for (int u = 0; u < 16; u += 2) {
+                    e = mzs_fma(wv[u], d[j + u], e);
+                    o = mzs_fma(wv[u + 1], d[j + u + 1], o);
+                }
+            }
             for (; j + 1 < nout; j += 2) {
                 e = mzs_fma(W[(size_t)j * ld + k], d[j], e);
                 o = mzs_fma(W[(size_t)(j + 1) * ld + k], d[j + 1], o);
