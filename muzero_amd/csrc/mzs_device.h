@@ -361,9 +361,13 @@ namespace mzs {
 
 /* Representation_function.forward: input in L.xh[0..obs) (vision model: the image at obs_g, global),
  * hidden state to L.xh and gdst */
+/* kVision: the kernels are instantiated once for the vision model and once for the others, so that
+ * the convolutions' register appetite (dozens of taps in flight) does not cost the MLP / LSTM
+ * instantiation its occupancy */
+template <bool kVision>
 __device__ __forceinline__ void model_representation(const Model& m, const WaveLds& L, const float* obs_g,
                                                      float* gdst, int lane) {
-    if (m.kind == MZS_MODEL_VISION) {
+    if constexpr (kVision) {
         vis_representation(m, L, obs_g, gdst, lane);
         return;
     }
@@ -380,9 +384,10 @@ __device__ __forceinline__ void model_representation(const Model& m, const WaveL
 
 /* Dynamics_function.forward on L.xh + action: reward returned (uniform), next hidden
  * state to L.xh and gdst */
+template <bool kVision>
 __device__ __forceinline__ float model_dynamics(const Model& m, const WaveLds& L, int action,
                                                 float* gdst, int lane) {
-    if (m.kind == MZS_MODEL_VISION) return vis_dynamics(m, L, action, gdst, lane);
+    if constexpr (kVision) return vis_dynamics(m, L, action, gdst, lane);
     if (m.kind == MZS_MODEL_LSTM) {
         const float* r = lstm_head(m, m.l_rew, L, L.xh, m.Sd + action, lane);
         const float reward = seg_support_scalar(r, m.Sd, lane);
@@ -400,9 +405,10 @@ __device__ __forceinline__ float model_dynamics(const Model& m, const WaveLds& L
 }
 
 /* Prediction_function.forward on L.xh: softmax policy as lane pairs, value (uniform) */
+template <bool kVision>
 __device__ __forceinline__ float model_prediction(const Model& m, const WaveLds& L, Pair* policy,
                                                   int lane) {
-    if (m.kind == MZS_MODEL_VISION) return vis_prediction(m, L, policy, lane);
+    if constexpr (kVision) return vis_prediction(m, L, policy, lane);
     if (m.kind == MZS_MODEL_LSTM) {
         const float* pl = lstm_head(m, m.l_pol, L, L.xh, -1, lane);
         *policy = seg_softmax(seg_load(pl, m.A, lane));

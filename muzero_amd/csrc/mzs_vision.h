@@ -27,9 +27,66 @@ constexpr int kVisC = MZS_VIS_C, kVisHidden = MZS_VIS_HIDDEN, kVisPix = MZS_VIS_
 constexpr int kVisBuf = 2432;  /* floats of one scratch map: >= 49 * 49, >= 3 * 25 * 25 */
 constexpr int kVisXh = 208;    /* hidden state (147) + action plane (49), rounded */
 
-/* out [Co][So][So] = conv3x3(in [Ci][Si][Si]), stride s, padding 1, no bias; in: LDS or global */
+/* out [Co][So][So] = conv3x3(in [Ci][Si][Si]), stride s, padding 1, no bias; in: LDS or global.
+ * One output per lane and pass; its Ci x 9 taps are all fetched (inputs and weights; a padding tap
+ * reads a clamped address and is marked) BEFORE the fma chain that consumes them in (ci, ky, kx)
+ * order, padding taps skipped by a select — the wave is alone on its SIMD, so a chain that waits for
+ * a load per tap (as the plain loop did) is bound by 27-36 load latencies per output. */
+template <int CI>
+__device__ __forceinline__ void vis_conv3_t(const float* __restrict__ w, const float* in, int Si, int Co, int s,
+                                            float* out, int lane) {
+    const int So = (Si - 1) / s + 1, n = So * So;
+    for (int idx0 = 0; idx0 < Co * n; idx0 += kWave) {
+        const int idx = idx0 + lane;
+        const bool live = idx < Co * n;
+        const int id = live ? idx : 0;
+        const int co = id / n, r = id - co * n, oy = r / So, ox = r - oy * So;
+        float xv[CI * 9], wv[CI * 9];
+        bool ok[9];
+        int off[9];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int iy = oy * s + ky - 1, ix = ox * s + kx - 1;
+                const bool v = iy >= 0 && iy < Si && ix >= 0 && ix < Si;
+                ok[ky * 3 + kx] = v;
+                off[ky * 3 + kx] = v ? iy * Si + ix : 0;
+            }
+        }
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+            const float* __restrict__ wk = w + (co * CI + ci) * 9;
+            const float* ip = in + (size_t)ci * Si * Si;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                wv[ci * 9 + t] = wk[t];
+                xv[ci * 9 + t] = ip[off[t]];
+            }
+        }
+        float acc = 0.0f;
+#pragma unroll
+        for (int ci = 0; ci < CI; ++ci) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const float a2 = mzs_fma(wv[ci * 9 + t], xv[ci * 9 + t], acc);
+                acc = ok[t] ? a2 : acc;
+            }
+        }
+        if (live) out[idx] = acc;
+    }
+    wave_sync();
+}
+
 __device__ __forceinline__ void vis_conv3(const float* __restrict__ w, const float* in, int Ci, int Si, int Co, int s,
                                           float* out, int lane) {
+    switch (Ci) { /* the model's channel counts: C / 2, C, C + 1 with C = MZS_VIS_C */
+        case 1: vis_conv3_t<1>(w, in, Si, Co, s, out, lane); return;
+        case 2: vis_conv3_t<2>(w, in, Si, Co, s, out, lane); return;
+        case 3: vis_conv3_t<3>(w, in, Si, Co, s, out, lane); return;
+        case 4: vis_conv3_t<4>(w, in, Si, Co, s, out, lane); return;
+        default: break;
+    }
     const int So = (Si - 1) / s + 1, n = So * So;
     for (int idx = lane; idx < Co * n; idx += kWave) {
         const int co = idx / n, r = idx - co * n, oy = r / So, ox = r - oy * So;
@@ -57,10 +114,31 @@ __device__ __forceinline__ void vis_conv3(const float* __restrict__ w, const flo
 /* out = relu(batchnorm(in)) on [C][n], eval mode */
 __device__ __forceinline__ void vis_bn_relu(const float* __restrict__ blob, const mzs_vis_bn& bn, const float* in, int C,
                                             int n, float* out, int lane) {
+    /* the per-channel constants once per call (C <= kVisC + 1 channels, their loads in flight together),
+     * not once per element: gamma / sqrt(var + eps) is the same value either way */
+    constexpr int CM = kVisC + 1;
+    float inv[CM], mu[CM], be[CM];
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        const int cc = c < C ? c : 0;
+        inv[c] = blob[bn.w + cc], mu[c] = blob[bn.var + cc], be[c] = blob[bn.b + cc];
+    }
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        const int cc = c < C ? c : 0;
+        inv[c] = inv[c] / __builtin_sqrtf(mu[c] + 1e-5f);
+        mu[c] = blob[bn.mean + cc];
+    }
     for (int idx = lane; idx < C * n; idx += kWave) {
         const int c = idx / n;
-        const float inv = blob[bn.w + c] / __builtin_sqrtf(blob[bn.var + c] + 1e-5f);
-        const float y = mzs_fma(in[idx] - blob[bn.mean + c], inv, blob[bn.b + c]);
+        float iv = inv[0], m0 = mu[0], b0 = be[0];
+#pragma unroll
+        for (int k = 1; k < CM; ++k) {
+            iv = c == k ? inv[k] : iv;
+            m0 = c == k ? mu[k] : m0;
+            b0 = c == k ? be[k] : b0;
+        }
+        const float y = mzs_fma(in[idx] - m0, iv, b0);
         out[idx] = y > 0.0f ? y : 0.0f;
     }
     wave_sync();
@@ -109,6 +187,16 @@ __device__ __forceinline__ void vis_linear(const float* __restrict__ W, const fl
         const float* __restrict__ w = W + (size_t)j * nin;
         float e = b[j], o = 0.0f;
         int k = 0;
+        for (; k + 15 < nin; k += 16) { /* sixteen weights in flight ahead of the chains (load latency) */
+            float wv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) wv[u] = w[k + u];
+#pragma unroll
+            for (int u = 0; u < 16; u += 2) {
+                e = mzs_fma(wv[u], x[k + u], e);
+                o = mzs_fma(wv[u + 1], x[k + u + 1], o);
+            }
+        }
         for (; k + 1 < nin; k += 2) {
             e = mzs_fma(w[k], x[k], e);
             o = mzs_fma(w[k + 1], x[k + 1], o);
@@ -126,8 +214,19 @@ __device__ __forceinline__ void vis_head_mlp(const Model& m, const float* __rest
                                              float* t2, int lane) {
     for (int idx = lane; idx < kVisC * kVisPix; idx += kWave) {
         const int co = idx / kVisPix, i = idx - co * kVisPix;
+        constexpr int CM = kVisC + 1;
+        float wv[CM], xv[CM]; /* the taps' loads in flight together, then the chain */
+#pragma unroll
+        for (int ci = 0; ci < CM; ++ci) {
+            const int cc = ci < Ci ? ci : 0;
+            wv[ci] = blob[conv_w + co * Ci + cc], xv[ci] = x[cc * kVisPix + i];
+        }
         float acc = blob[conv_b + co];
-        for (int ci = 0; ci < Ci; ++ci) acc = mzs_fma(blob[conv_w + co * Ci + ci], x[ci * kVisPix + i], acc);
+#pragma unroll
+        for (int ci = 0; ci < CM; ++ci) {
+            const float a2 = mzs_fma(wv[ci], xv[ci], acc);
+            acc = ci < Ci ? a2 : acc;
+        }
         t1[idx] = acc;
     }
     wave_sync();

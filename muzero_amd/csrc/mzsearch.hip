@@ -109,8 +109,8 @@ __device__ __forceinline__ void pair_to_global(float* row, const Pair p, int lan
  * one game per wavefront, all simulations in one launch, tree resident in LDS and
  * written to the HBM structure-of-arrays once at the end.
  * ---------------------------------------------------------------------------- */
-template <bool kInjected>
-__global__ void __launch_bounds__(256) k_search_fused(const SearchParams p) {
+template <bool kInjected, bool kVision = false>
+__global__ void __launch_bounds__(256, kVision ? 1 : 4) k_search_fused(const SearchParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
@@ -163,12 +163,12 @@ __global__ void __launch_bounds__(256) k_search_fused(const SearchParams p) {
         pol = pair_from_global(p.t_root_policy + (size_t)g * A, A, lane);
     } else {
         /* vision model: the image stays in global memory (3 x 98 x 98 floats per game) */
-        const size_t obs_floats = m.kind == MZS_MODEL_VISION ? (size_t)MZS_VIS_C * m.obs_dim * m.obs_dim : (size_t)m.obs_dim;
-        if (m.kind != MZS_MODEL_VISION)
+        const size_t obs_floats = kVision ? (size_t)MZS_VIS_C * m.obs_dim * m.obs_dim : (size_t)m.obs_dim;
+        if (!kVision)
             for (int k = lane; k < m.obs_dim; k += kWave) L.xh[k] = p.obs[(size_t)g * m.obs_dim + k];
         wave_sync();
-        model_representation(m, L, p.obs + (size_t)g * obs_floats, hid_g, lane);
-        (void)model_prediction(m, L, &pol, lane);
+        model_representation<kVision>(m, L, p.obs + (size_t)g * obs_floats, hid_g, lane);
+        (void)model_prediction<kVision>(m, L, &pol, lane);
     }
     wave_expand(c, L, 0, 0, 0.0f, pol, lane);
     /* add_exploration_noise_at_the_root (mcts.py:134-145): f32 product widened, f64 sum */
@@ -195,8 +195,8 @@ __global__ void __launch_bounds__(256) k_search_fused(const SearchParams p) {
             const float* hp = hid_g + (size_t)e_parent * p.t.hid_stride;
             for (int k = lane; k < m.hid; k += kWave) L.xh[k] = hp[k];
             wave_sync();
-            reward = model_dynamics(m, L, action, hid_g + (size_t)e_new * p.t.hid_stride, lane);
-            value = model_prediction(m, L, &pol, lane);
+            reward = model_dynamics<kVision>(m, L, action, hid_g + (size_t)e_new * p.t.hid_stride, lane);
+            value = model_prediction<kVision>(m, L, &pol, lane);
         }
         wave_expand(c, L, leaf, e_new, reward, pol, lane);
         if (lane == 0) p.t.sim_leaf[(size_t)g * p.t.max_sims + sim] = leaf;
@@ -492,7 +492,7 @@ struct InferParams {
 
 enum { kInferInitial = 0, kInferRecurrent = 1, kInferPrediction = 2 };
 
-template <int kMode>
+template <int kMode, bool kVision = false>
 __global__ void __launch_bounds__(256) k_inference(const InferParams p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
@@ -501,22 +501,22 @@ __global__ void __launch_bounds__(256) k_inference(const InferParams p) {
     if (b >= p.batch) return;
     const WaveLds L = carve(smem + (size_t)wave * p.lds.bytes, p.lds);
     const Model& m = p.m;
-    const bool vision = m.kind == MZS_MODEL_VISION;
+    constexpr bool vision = kVision;
     const size_t obs_floats = vision ? (size_t)MZS_VIS_C * m.obs_dim * m.obs_dim : (size_t)m.obs_dim;
     const int n_in = kMode == kInferInitial ? (vision ? 0 : m.obs_dim) : m.hid;
     for (int k = lane; k < n_in; k += kWave) L.xh[k] = p.in[(size_t)b * n_in + k];
     wave_sync();
     if (kMode == kInferInitial) {
-        model_representation(m, L, p.in + (size_t)b * obs_floats, nullptr, lane);
+        model_representation<kVision>(m, L, p.in + (size_t)b * obs_floats, nullptr, lane);
     } else if (kMode == kInferRecurrent) {
-        const float reward = model_dynamics(m, L, p.action[b], nullptr, lane);
+        const float reward = model_dynamics<kVision>(m, L, p.action[b], nullptr, lane);
         if (lane == 0) p.reward[b] = reward;
     }
     if (kMode != kInferPrediction)
         for (int k = lane; k < m.hid; k += kWave) p.hidden_out[(size_t)b * m.hid + k] = L.xh[k];
     if (p.policy || p.value) {
         Pair pol;
-        const float value = model_prediction(m, L, &pol, lane);
+        const float value = model_prediction<kVision>(m, L, &pol, lane);
         if (p.policy) pair_to_global(p.policy + (size_t)b * m.A, pol, lane);
         if (p.value && lane == 0) p.value[b] = value;
     }
@@ -1129,7 +1129,7 @@ SearchPlan plan_search(const mzs_handle* h, int S, int n_games) {
     const mzs_dims& d = h->cfg.dims;
     const int A = d.n_actions, n_nodes = mzs_nodes_per_game(A, S);
     pl.kind = kPlanGeneric;
-    std::snprintf(pl.name, sizeof pl.name, "k_search_fused<false>");
+    std::snprintf(pl.name, sizeof pl.name, d.model_kind == MZS_MODEL_VISION ? "k_search_fused<false,vision>" : "k_search_fused<false>");
     if (h->cfg.engine != MZS_ENGINE_FUSED || mzs_max_draws(A, S) >= (1ll << 31)) return pl;
     static const bool no_occ2 = std::getenv("MZS_NO_OCC2") != nullptr; /* measurement knob: same results either way */
     if ((n_games + 15) / 16 > h->n_cus && !no_occ2) {
@@ -1463,7 +1463,9 @@ static int search_launch(mzs_handle* h, int32_t n_games, int32_t S, int32_t trai
     p.overflow = h->overflow_dev;
     p.redo = redo;
     const SearchPlan plan = plan_search(h, S, n_games);
-    if (plan.kind == kPlanGeneric) return launch(k_search_fused<false>, p, n_games, p.lds, st);
+    if (plan.kind == kPlanGeneric)
+        return h->cfg.dims.model_kind == MZS_MODEL_VISION ? launch(k_search_fused<false, true>, p, n_games, p.lds, st)
+                                                          : launch(k_search_fused<false>, p, n_games, p.lds, st);
     if (plan.kind == kPlanStream) {
         if (build_stream) {
             hipLaunchKernelGGL(k_build_stream, dim3(h->stream_plan.n), dim3(256), 0, st, h->w_search_dev,
@@ -1679,6 +1681,11 @@ static int run_inference(mzs_handle* h, int mode, int32_t batch, const float* in
     p.policy = policy;
     p.value = value;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (h->cfg.dims.model_kind == MZS_MODEL_VISION) {
+        if (mode == kInferInitial) return launch(k_inference<kInferInitial, true>, p, batch, p.lds, st);
+        if (mode == kInferRecurrent) return launch(k_inference<kInferRecurrent, true>, p, batch, p.lds, st);
+        return launch(k_inference<kInferPrediction, true>, p, batch, p.lds, st);
+    }
     if (mode == kInferInitial) return launch(k_inference<kInferInitial>, p, batch, p.lds, st);
     if (mode == kInferRecurrent) return launch(k_inference<kInferRecurrent>, p, batch, p.lds, st);
     return launch(k_inference<kInferPrediction>, p, batch, p.lds, st);
