@@ -228,6 +228,18 @@ int mzs_train_grad_static(mzs_handle* h, int32_t batch, int32_t unroll_steps, co
                           const float* is_ratio_dev, float inv_global_batch, float* grad_dev, float* loss_dev,
                           float* priority_dev, void* stream);
 
+/* The criteria of the value and reward terms of evaluate_loss, i.e. the reference's loss_type
+ * (init_criterion_and_optimizer, muzero_model.py:350-403; Loss_function, neural_network_mlp_model.py:
+ * 236-262, always on softmax(logits) + 1e-9): 'general' = CE / CE (the default), 'general_kkc' =
+ * KL / KL (log(target + 1e-9): NaN for negative targets, as in the reference), 'game' = MSE / ZERO,
+ * 'game_mmc' = MSE / MSE.  The policy term is the cross-entropy in all of them.  Applies to every later
+ * mzs_train_grad / mzs_train_grad_static on the handle. */
+#define MZS_LOSS_CE 0
+#define MZS_LOSS_KL 1
+#define MZS_LOSS_MSE 2
+#define MZS_LOSS_ZERO 3
+int mzs_train_set_loss(mzs_handle* h, int32_t value_criterion, int32_t reward_criterion);
+
 /* optimizer.step() (muzero_model.py:764) with the (all-reduced) gradient; lr is the scheduler's
  * current value (muzero_amd/train.py evaluates the reference's schedulers on the host). */
 int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, double lr, void* stream);

@@ -53,6 +53,7 @@ struct TrainParams {
     mzs_blob_offsets bo;
     const float* blob; /* master weights, torch layout (include/mzs_layout.h) */
     int B, K, n_params;
+    int loss_value, loss_reward; /* MZS_LOSS_*: criterion of the value / reward terms (mzs_train_set_loss) */
     float inv_batch;
     const float* obs;
     const float* actions;
@@ -183,11 +184,15 @@ __device__ __forceinline__ void train_support_target(float x, int S, int* idx, f
     *weight = (ceilf(t) - t) * sg;
 }
 
-/* Loss_function.cross_entropy (neural_network_mlp_model.py:240-243) of softmax(z) + 1e-9 against
- * target p (this lane's entry); delta = upstream * dloss/dz to dz[0..n).  Returns the loss
- * (uniform); *softmax_out = this lane's softmax probability. */
+/* One loss term of evaluate_loss (muzero_model.py:650-700): criterion `mode` (MZS_LOSS_*, the
+ * Loss_function methods of neural_network_mlp_model.py:236-262) of q = softmax(z) + 1e-9 against the
+ * target p (this lane's entry); delta = upstream * dloss/dz to dz[0..n).  With c = dloss/dq:
+ *   CE  -sum p log q, c = -p / q          KL  sum p' (log p' - log q), p' = p + 1e-9, c = -p' / q
+ *   MSE mean (p - q)^2, c = -2 (p - q) / n          ZERO 0, c = 0
+ * and dloss/dz = s (c - sum c s).  Returns the loss (uniform); *softmax_out = this lane's softmax
+ * probability. */
 __device__ __forceinline__ float train_ce(const float* z, int n, float p, float upstream, float* dz,
-                                          float* softmax_out, int lane) {
+                                          float* softmax_out, int lane, int mode = MZS_LOSS_CE) {
     const bool valid = lane < n;
     const float zv = valid ? z[lane] : 0.0f;
     const float m = wave_max(valid ? zv : -__builtin_inff());
@@ -196,9 +201,24 @@ __device__ __forceinline__ float train_ce(const float* z, int n, float p, float 
     const float s = e / Z;
     const float q = s + 1e-9f;
     const float pv = valid ? p : 0.0f;
-    const float c = -pv / q;
-    const float loss = train_sum(valid ? -pv * logf(q) : 0.0f);
-    const float dot = train_sum(c * s);
+    float c, term;
+    if (mode == MZS_LOSS_CE) {
+        c = -pv / q;
+        term = -pv * logf(q);
+    } else if (mode == MZS_LOSS_KL) {
+        const float pp = pv + 1e-9f;
+        c = -pp / q;
+        term = pp * (logf(pp) - logf(q));
+    } else if (mode == MZS_LOSS_MSE) {
+        const float d = pv - q;
+        c = -2.0f * d / (float)n;
+        term = d * d / (float)n;
+    } else {
+        c = 0.0f;
+        term = 0.0f;
+    }
+    const float loss = train_sum(valid ? term : 0.0f);
+    const float dot = train_sum(valid ? c * s : 0.0f);
     if (valid) dz[lane] = upstream * s * (c - dot);
     *softmax_out = s;
     wave_sync();
@@ -289,7 +309,7 @@ __global__ void __launch_bounds__(64) k_train_sample(const TrainParams p) {
         const float tvk = p.tv[(size_t)k * B + b];
         train_support_target(tvk, S, &idx, &wt);
         const float lv = train_ce(P + t.p_out + m.seg_value, S, lane == idx ? wt : 0.0f, gs, P + t.p_dval,
-                                  &sm, lane);
+                                  &sm, lane, p.loss_value);
         {
             /* new_priority (muzero_model.py:710-713): |h^-1(value) - target| */
             const float y = train_sum(lane < S ? (float)(lane - S / 2) * sm : 0.0f);
@@ -313,7 +333,8 @@ __global__ void __launch_bounds__(64) k_train_sample(const TrainParams p) {
             wave_sync();
             train_scale_bwd(gh, P + t.p_h, S, scl[k], D + t.d_dst, lane);
             train_support_target(p.tr[(size_t)k * B + b], S, &idx, &wt);
-            const float lr = train_ce(D + t.d_out, S, lane == idx ? wt : 0.0f, gs, D + t.d_drew, &sm, lane);
+            const float lr = train_ce(D + t.d_out, S, lane == idx ? wt : 0.0f, gs, D + t.d_drew, &sm, lane,
+                                      p.loss_reward);
             if (lane == 0) p.loss_buf[(size_t)b * n_terms + t0 + 2] = lr;
             train_back_input(bl + o.d_st_w, S, H, H, D + t.d_dst, gT, false, lane);
             train_back_input(bl + o.d_rew_w, S, H, H, D + t.d_drew, gT, true, lane);

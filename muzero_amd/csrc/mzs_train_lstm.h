@@ -63,6 +63,7 @@ struct LstmTrainParams {
     const float* blob;
     int B, Bcap, K, L, H, Sd, A, obs_dim, n_params;
     int r_w, r_b;
+    int loss_value, loss_reward; /* MZS_LOSS_* (mzs_train_set_loss) */
     float inv_batch;
     const float *obs, *actions, *tv, *tr, *tp, *is_ratio;
     float* tape;
@@ -503,7 +504,8 @@ __global__ void __launch_bounds__(kLstmTrainThreads) k_lstm_heads(const LstmTrai
             int idx;
             float wt;
             train_support_target(target, S, &idx, &wt);
-            const float lv = train_ce(out + (size_t)t * S, S, lane == idx ? wt : 0.0f, gs, dout + (size_t)t * S, &sm, lane);
+            const float lv = train_ce(out + (size_t)t * S, S, lane == idx ? wt : 0.0f, gs, dout + (size_t)t * S, &sm, lane,
+                                      hd == kHeadVal ? p.loss_value : p.loss_reward);
             if (lane == 0) p.loss_buf[(size_t)t * n_terms + t0 + (hd == kHeadVal ? 0 : 2)] = lv;
             if (hd == kHeadVal) { /* new_priority (muzero_model.py:710-713) */
                 const float y = train_sum(lane < S ? (float)(lane - S / 2) * sm : 0.0f);

@@ -745,6 +745,7 @@ struct mzs_handle {
     float* adam_v_dev = nullptr;
     double* wgrad_partial_dev = nullptr;
     LstmTrainParams lstm_train;    /* 'lstm_model': tape layout and descriptor tables of mzs_train_create */
+    int loss_value = MZS_LOSS_CE, loss_reward = MZS_LOSS_CE; /* mzs_train_set_loss */
     size_t w_floats = 0;
     bool have_weights = false;
     int n_nodes_max = 0;
@@ -1930,6 +1931,7 @@ static int lstm_train_grad_launch(mzs_handle* h, int32_t batch, const float* obs
                                   float* grad_dev, float* loss_dev, float* priority_dev, hipStream_t st) {
     LstmTrainParams p = h->lstm_train;
     p.B = batch;
+    p.loss_value = h->loss_value, p.loss_reward = h->loss_reward;
     p.inv_batch = inv_global_batch;
     p.obs = obs_dev, p.actions = actions_dev, p.tv = target_value_dev, p.tr = target_reward_dev;
     p.tp = target_policy_dev, p.is_ratio = is_ratio_dev;
@@ -2000,6 +2002,7 @@ static int train_grad_launch(mzs_handle* h, const TapeLayout& tl, int K, int32_t
     p.B = batch;
     p.K = K;
     p.n_params = (int)p.bo.total;
+    p.loss_value = h->loss_value, p.loss_reward = h->loss_reward;
     p.inv_batch = inv_global_batch;
     p.obs = obs_dev;
     p.actions = actions_dev;
@@ -2101,6 +2104,14 @@ int mzs_train_grad_static(mzs_handle* h, int32_t batch, int32_t unroll_steps, co
     return train_grad_launch(h, tl, unroll_steps, batch, obs_dev, actions_dev, target_value_dev, target_reward_dev,
                              target_policy_dev, is_ratio_dev, inv_global_batch, grad_dev, loss_dev, priority_dev,
                              tape, loss_buf, partial, static_cast<hipStream_t>(stream));
+}
+
+int mzs_train_set_loss(mzs_handle* h, int32_t value_criterion, int32_t reward_criterion) {
+    if (!h) return fail(MZS_E_ARG, "null handle");
+    const auto ok = [](int v) { return v >= MZS_LOSS_CE && v <= MZS_LOSS_ZERO; };
+    if (!ok(value_criterion) || !ok(reward_criterion)) return fail(MZS_E_ARG, "unknown loss criterion (MZS_LOSS_*)");
+    h->loss_value = value_criterion, h->loss_reward = reward_criterion;
+    return MZS_OK;
 }
 
 int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, double lr, void* stream) {

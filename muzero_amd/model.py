@@ -407,9 +407,9 @@ class Muzero:
             raise NotImplementedError("train(): kernels exist for 'mlp_model' and 'lstm_model'; the vision model "
                                       "runs inference and search (its training mode draws Dropout2d masks from "
                                       "torch's generator and updates BatchNorm statistics: not built)")
-        if self.loss_type != "general":
-            raise NotImplementedError(f"loss_type={self.loss_type!r}: only the 'general' cross-entropy "
-                                      "losses every shipped config uses (muzero_model.py:350-361)")
+        if self.loss_type not in tr.LOSS_TYPES:
+            raise NotImplementedError(f"loss_type={self.loss_type!r}: the reference knows {sorted(tr.LOSS_TYPES)} "
+                                      "(muzero_model.py:350-403)")
         obs, actions, tv, trw, tp, ratio, game_pos = tr.reshape_batch(
             batch, self.observation_dimension, self.action_dimension, self.k_hypothetical_steps)
         B = obs.shape[0]
@@ -420,7 +420,7 @@ class Muzero:
                                       "model with the largest batch first")
         if self._trainer is None:
             self._trainer = tr.Trainer(self._inference_engine(), self.k_hypothetical_steps, B, self.opt, self.lr,
-                                       self.sch, self.epoch)
+                                       self.sch, self.epoch, self.loss_type)
         t = self._trainer
         t.count = self.count
         prio = t.step(obs, actions, tv, trw, tp, ratio)

@@ -604,7 +604,7 @@ class SelfPlay:
         eng.set_weights(mz.weights_blob())
         mz._engine = eng
         trainer = Trainer(eng, m["k_hypothetical_steps"], rb["batch_size"], m["optimizer"], m["learning_rate"],
-                          m["lr_scheduler"], m["num_of_epoch"])
+                          m["lr_scheduler"], m["num_of_epoch"], m["loss_type"])
         mz._trainer = trainer
         from .shard import rank_world
         if rank_world()[1] > 1:      # Trainer broadcast rank 0's weights into the handle: mz follows

@@ -82,11 +82,18 @@ def allreduce_gradient(grad, loss, group=None):
     return dist.get_world_size(group)
 
 
+# loss_type (init_criterion_and_optimizer, muzero_model.py:350-403) -> the criteria of the value and reward
+# terms (MZS_LOSS_CE / KL / MSE / ZERO of include/mzsearch.h); the policy term is always the cross-entropy
+LOSS_TYPES = {"general": (0, 0), "general_kkc": (1, 1), "game": (2, 3), "game_mmc": (2, 2)}
+
+
 class Trainer:
     """Owns the training state of one engine handle (one GPU)."""
 
     def __init__(self, engine, unroll_steps, max_batch, optimizer="adam", learning_rate=1e-3,
-                 lr_scheduler=None, num_of_epoch=300):
+                 lr_scheduler=None, num_of_epoch=300, loss_type="general"):
+        if loss_type not in LOSS_TYPES:
+            raise ValueError(f"loss_type={loss_type!r}: one of {sorted(LOSS_TYPES)} (muzero_model.py:350-403)")
         if optimizer not in OPTIMIZERS:
             raise ValueError(f"optimizer={optimizer!r}: 'adam' or 'sgd' (muzero_model.py:418-421)")
         if lr_scheduler not in SCHEDULERS:
@@ -97,6 +104,8 @@ class Trainer:
         self.opt, self.lr, self.sch, self.epoch = optimizer, float(learning_rate), lr_scheduler, num_of_epoch
         self.count = 0
         _lib.check(self.lib.mzs_train_create(engine.h, self.max_batch, self.K), "mzs_train_create")
+        self.loss_type = loss_type
+        _lib.check(self.lib.mzs_train_set_loss(engine.h, *LOSS_TYPES[loss_type]), "mzs_train_set_loss")
         dev, n = engine.device, engine.weight_count()
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.loss = torch.zeros(3 * self.K, dtype=torch.float32, device=dev)

@@ -116,6 +116,14 @@ typedef struct mzo_train_batch {
 /* Muzero.train up to (not including) the optimizer step: grad [total blob floats] (blob order),
  * loss_terms [3K-1] batch means of the raw terms in store_loss order, *total_loss = loss_nn,
  * priority [K][B] = |h^-1(value_k) - target_value_k| (muzero_model.py:710-713). */
+/* the criteria of the value and reward terms (loss_type, muzero_model.py:350-403: 'general' = CE / CE,
+ * 'general_kkc' = KL / KL, 'game' = MSE / ZERO, 'game_mmc' = MSE / MSE; the policy term is always CE);
+ * process-wide state of the oracle, default CE / CE */
+#define MZO_LOSS_CE 0
+#define MZO_LOSS_KL 1
+#define MZO_LOSS_MSE 2
+#define MZO_LOSS_ZERO 3
+void mzo_train_set_loss(int value_mode, int reward_mode);
 int mzo_train_grad(const mzs_dims* d, const float* blob, const mzo_train_batch* bt, float* grad,
                    float* loss_terms, double* total_loss, float* priority);
 void mzo_adam_step(float* w, float* m, float* v, const float* g, size_t n, int step, double lr);

@@ -213,10 +213,15 @@ def blob_size(d):
                blob_layout(d.obs_dim, d.n_actions, d.state_dim, d.hidden_dim, d.n_mid_layers, d.model_kind))
 
 
+# loss_type -> (criterion of the value term, of the reward term), muzero_model.py:350-403; MZO_LOSS_*
+LOSS_MODES = {"general": (0, 0), "general_kkc": (1, 1), "game": (2, 3), "game_mmc": (2, 2)}
+
+
 def train_grad(d, blob, obs, actions, target_value, target_reward, target_policy, is_ratio=None,
-               global_batch=None):
+               global_batch=None, loss_type="general"):
     """Forward + losses + backward of one training step on a batch (shard).  Returns
     dict(grad [P], loss_terms [3K-1], total_loss, priority [K, B])."""
+    lib().mzo_train_set_loss(*LOSS_MODES[loss_type])
     obs, actions = _f32(obs), _f32(actions)
     tv, tr, tp = _f32(target_value), _f32(target_reward), _f32(target_policy)
     K, B = tv.shape

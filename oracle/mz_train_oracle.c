@@ -131,8 +131,18 @@ static void support_target(float x, int S, int* idx, float* weight) {
     *weight = w;
 }
 
-/* cross entropy of softmax(z) + 1e-9 against p; gz += upstream * dloss/dz; returns the loss */
-static float ce_loss(const float* z, int n, const float* p, float upstream, float* gz, float* s) {
+/* One loss term of evaluate_loss (muzero_model.py:650-700) on q = softmax(z) + 1e-9 (the prediction
+ * transforms of every loss_type, muzero_model.py:350-403) against the target row p; gz += upstream *
+ * dloss/dz; returns the loss.  mode = the criterion (neural_network_mlp_model.py:236-262):
+ *   MZO_LOSS_CE    cross_entropy  -sum p log q                                  c = -p / q
+ *   MZO_LOSS_KL    kldiv          sum p' (log p' - log q), p' = p + 1e-9        c = -p' / q
+ *   MZO_LOSS_MSE   mse            mean (p - q)^2                                c = -2 (p - q) / n
+ *   MZO_LOSS_ZERO  zero_loss      0                                             c = 0
+ * with dloss/dz = s (c - sum c s), s = softmax(z). */
+static int g_loss_value = MZO_LOSS_CE, g_loss_reward = MZO_LOSS_CE;
+void mzo_train_set_loss(int value_mode, int reward_mode) { g_loss_value = value_mode, g_loss_reward = reward_mode; }
+
+static float loss_term(int mode, const float* z, int n, const float* p, float upstream, float* gz, float* s) {
     float m = z[0];
     for (int i = 1; i < n; ++i) m = z[i] > m ? z[i] : m;
     double Z = 0.0;
@@ -144,15 +154,34 @@ static float ce_loss(const float* z, int n, const float* p, float upstream, floa
     for (int i = 0; i < n; ++i) {
         s[i] = (float)(s[i] / Z);
         const float q = s[i] + 1e-9f;
-        loss += -(double)p[i] * log((double)q);
-        dot += (double)(-p[i] / q) * s[i];
+        double c = 0.0;
+        if (mode == MZO_LOSS_CE) {
+            loss += -(double)p[i] * log((double)q);
+            c = (double)(-p[i] / q);
+        } else if (mode == MZO_LOSS_KL) {
+            const float pp = p[i] + 1e-9f;
+            loss += (double)pp * (log((double)pp) - log((double)q));
+            c = (double)(-pp / q);
+        } else if (mode == MZO_LOSS_MSE) {
+            const double d = (double)p[i] - (double)q;
+            loss += d * d / n;
+            c = -2.0 * d / n;
+        }
+        dot += c * s[i];
     }
     if (gz)
         for (int i = 0; i < n; ++i) {
             const float q = s[i] + 1e-9f;
-            gz[i] += upstream * s[i] * (float)((double)(-p[i] / q) - dot);
+            double c = 0.0;
+            if (mode == MZO_LOSS_CE) c = (double)(-p[i] / q);
+            else if (mode == MZO_LOSS_KL) c = (double)(-(p[i] + 1e-9f) / q);
+            else if (mode == MZO_LOSS_MSE) c = -2.0 * ((double)p[i] - (double)q) / n;
+            gz[i] += upstream * s[i] * (float)(c - dot);
         }
     return (float)loss;
+}
+static float ce_loss(const float* z, int n, const float* p, float upstream, float* gz, float* s) {
+    return loss_term(MZO_LOSS_CE, z, n, p, upstream, gz, s);
 }
 
 /* ================================================================== 'lstm_model' ==========
@@ -348,7 +377,7 @@ static int lstm_train_grad(const mzs_dims* d, const float* blob, const mzo_train
             support_target(bt->target_value[(size_t)k * B + b], S, &idx, &wt);
             for (int i = 0; i < S; ++i) ptar[i] = 0.0f;
             ptar[idx] = wt;
-            const float lv = ce_loss(val + (size_t)b * S, S, ptar, gs, dV + (size_t)b * S, sm);
+            const float lv = loss_term(g_loss_value, val + (size_t)b * S, S, ptar, gs, dV + (size_t)b * S, sm);
             const float lp = ce_loss(pol + (size_t)b * A, A, bt->target_policy + ((size_t)k * B + b) * A, gs,
                                      dP + (size_t)b * A, sm);
             loss_terms[t0] += lv * bt->inv_batch;
@@ -360,7 +389,7 @@ static int lstm_train_grad(const mzs_dims* d, const float* blob, const mzo_train
                 support_target(bt->target_reward[(size_t)k * B + b], S, &idx, &wt);
                 for (int i = 0; i < S; ++i) ptar[i] = 0.0f;
                 ptar[idx] = wt;
-                const float lr = ce_loss(rew + (size_t)b * S, S, ptar, gs, dR + (size_t)b * S, sm);
+                const float lr = loss_term(g_loss_reward, rew + (size_t)b * S, S, ptar, gs, dR + (size_t)b * S, sm);
                 loss_terms[t0 + 2] += lr * bt->inv_batch;
                 sample_loss[b] += lr;
             }
@@ -481,7 +510,7 @@ int mzo_train_grad(const mzs_dims* d, const float* blob, const mzo_train_batch* 
             for (int i = 0; i < S; ++i) ptar[i] = 0.0f;
             ptar[idx] = wt;
             for (int i = 0; i < S; ++i) gz[i] = 0.0f;
-            float lv = ce_loss(val + (size_t)k * S, S, ptar, gs, gz, sm);
+            float lv = loss_term(g_loss_value, val + (size_t)k * S, S, ptar, gs, gz, sm);
             /* policy */
             for (int i = 0; i < A; ++i) gz2[i] = 0.0f;
             float lp = ce_loss(pol + (size_t)k * A, A, bt->target_policy + ((size_t)k * B + b) * A, gs,
@@ -507,7 +536,7 @@ int mzo_train_grad(const mzs_dims* d, const float* blob, const mzo_train_batch* 
                 for (int i = 0; i < S; ++i) ptar[i] = 0.0f;
                 ptar[idx] = wt;
                 for (int i = 0; i < S; ++i) gz2[i] = 0.0f;
-                float lr = ce_loss(rew + (size_t)k * S, S, ptar, gs, gz2, sm);
+                float lr = loss_term(g_loss_reward, rew + (size_t)k * S, S, ptar, gs, gz2, sm);
                 loss_terms[t0 + 2] += lr * bt->inv_batch;
                 sample_loss += lr;
                 const float* td = TD + TH * (k - 1);

@@ -4,7 +4,8 @@ import numpy as np
 import pytest
 
 from conftest import load_golden
-from test_train_oracle import GRAD_REL, LOSS_REL, TRAIN_FIXTURES, check_against_fixture, step_inputs
+from test_train_oracle import (GRAD_REL, LOSS_REL, TRAIN_FIXTURES, check_against_fixture, loss_type_of,
+                               step_inputs)
 
 pytestmark = pytest.mark.gpu
 
@@ -17,7 +18,7 @@ def make_trainer(fx):
     eng = SearchEngine(dims, max_games=1, max_simulations=0)
     eng.set_weights(fx["blob0"])
     tr = Trainer(eng, int(fx["K"]), int(fx["B"]), str(fx["optimizer"]), float(fx["lr"]),
-                 None if sch == "none" else sch, int(fx["epoch"]))
+                 None if sch == "none" else sch, int(fx["epoch"]), loss_type_of(fx))
     return eng, tr
 
 
@@ -43,7 +44,7 @@ def test_train_step_vs_oracle_and_reference(fname):
         tr.grad_step(inp["obs"], inp["actions"], inp["target_value"], inp["target_reward"],
                      inp["target_policy"], inp["is_ratio"])
         got = gpu_out(tr, B)
-        ref = mzo.train_grad(d, blob_before, **inp)
+        ref = mzo.train_grad(d, blob_before, **inp, loss_type=loss_type_of(fx))
         assert abs(got["total_loss"] - ref["total_loss"]) <= LOSS_REL * abs(ref["total_loss"])
         assert np.all(np.abs(got["loss_terms"] - ref["loss_terms"]) <= LOSS_REL * np.abs(ref["loss_terms"]) + 1e-7)
         assert np.abs(got["grad"] - ref["grad"]).max() <= GRAD_REL * np.abs(ref["grad"]).max()
@@ -200,6 +201,37 @@ def test_muzero_train_drop_in():
             assert np.all(np.abs(got - L) <= 2e-3 * np.abs(L) + 1e-4)
         assert np.abs(mz.weights_blob() - fx[f"s{s}_blob"]).max() <= (s + 1) * 2e-3 * 0.01 + 1e-6
     assert mz.count == 2
+
+
+@pytest.mark.parametrize("loss_type", ["general_kkc", "game", "game_mmc"])
+def test_muzero_train_drop_in_other_loss_types(loss_type):
+    """Muzero(loss_type=...).train: the reference's KL / MSE / zero criteria (muzero_model.py:364-403)
+    through the drop-in surface: the first step's store_loss entry and priorities against the
+    reference's own Muzero.train on the same batch and weights."""
+    import torch
+    from muzero_amd.model import Muzero
+    fx = load_golden(f"train_loss_{loss_type}_K3_B24.npz")
+    mz = Muzero(model_structure="mlp_model", observation_space_dimensions=4, action_space_dimensions=2,
+                state_space_dimensions=31, hidden_layer_dimensions=64, number_of_hidden_layer=1,
+                k_hypothetical_steps=3, learning_rate=0.003, optimizer="adam", lr_scheduler=None, num_of_epoch=100,
+                loss_type=loss_type)
+    mz.set_weights(fx["blob0"])
+    K, B, A = fx["s0_actions"].shape
+    batch = []
+    for b in range(B):
+        acts = [fx["s0_actions"][k, b] for k in range(K)]
+        tg = [[float(fx["s0_target_value"][k, b]), float(fx["s0_target_reward"][k, b]), fx["s0_target_policy"][k, b]]
+              for k in range(K)]
+        batch.append((torch.tensor(fx["s0_obs"][b:b + 1]), acts, tg))
+    pos = np.stack([np.arange(B), np.arange(B)], axis=1)
+    prio, _ = mz.train((batch, fx["s0_is_ratio"], pos))
+    L = fx["s0_losses"]
+    got = np.array([float(x) for x in mz.store_loss[-1]])
+    assert np.all(np.abs(got - L) <= 1e-5 * np.abs(L) + 1e-7)
+    if loss_type == "game":
+        assert np.all(got[[5, 8]] == 0)                      # zero_loss on the reward terms
+    ref = fx["s0_priority"]
+    assert np.all(np.abs(np.stack([p[:, 0] for p in prio]) - ref) <= 1e-5 * (1 + np.abs(ref)) + 1e-3)
 
 
 def test_training_refreshes_the_weight_stream():

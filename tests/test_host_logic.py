@@ -76,7 +76,7 @@ def test_blob_layout_and_model_wrapper():
     nw = lz.named_weights()
     assert nw["d_rew_w_ih_l1"].shape == (124, 31) and nw["p_pol_w_hh_l0"].shape == (8, 2)
     assert np.abs(nw["p_val_w_ih_l0"]).max() <= 1 / np.sqrt(31) and abs(nw["r_w"].std() - 1 / 137.035999) < 2e-3
-    lz.loss_type = "kldiv"           # train(): only the 'general' cross-entropy losses have kernels
+    lz.loss_type = "kldiv"           # train(): not one of the reference's loss types
     with pytest.raises(NotImplementedError):
         lz.train(None)
 
