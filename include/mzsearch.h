@@ -240,6 +240,11 @@ int mzs_train_grad_static(mzs_handle* h, int32_t batch, int32_t unroll_steps, co
 #define MZS_LOSS_ZERO 3
 int mzs_train_set_loss(mzs_handle* h, int32_t value_criterion, int32_t reward_criterion);
 
+/* Adam's beta1 / SGD's momentum for the following mzs_train_apply calls (default 0.9, what
+ * muzero_model.py:418-421 constructs).  OneCycleLR (muzero_model.py:433) cycles it per step together
+ * with the rate: the caller evaluates both on the host (muzero_amd/train.py) and passes them in. */
+int mzs_train_set_momentum(mzs_handle* h, double momentum);
+
 /* optimizer.step() (muzero_model.py:764) with the (all-reduced) gradient; lr is the scheduler's
  * current value (muzero_amd/train.py evaluates the reference's schedulers on the host). */
 int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, double lr, void* stream);

@@ -85,6 +85,7 @@ _SIGNATURES = {
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p]),
     "mzs_train_set_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
+    "mzs_train_set_momentum": (C.c_int, [C.c_void_p, C.c_double]),
     "mzs_train_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
     "mzs_get_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mzs_arena_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

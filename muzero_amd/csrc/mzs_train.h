@@ -460,9 +460,10 @@ struct ApplyParams {
     const float* grad;
     int n, optimizer, step;
     float lr_over_bc1, inv_sqrt_bc2, lr;
+    float momentum, one_minus_momentum; /* Adam beta1 / SGD momentum (0.9 unless OneCycleLR cycles it) */
 };
 
-/* torch.optim.Adam (betas 0.9/0.999, eps 1e-8) or SGD(momentum 0.9); refreshes the transposed
+/* torch.optim.Adam (betas momentum/0.999, eps 1e-8) or SGD(momentum); refreshes the transposed
  * store the search kernels read */
 __global__ void __launch_bounds__(256) k_train_apply(const ApplyParams p) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -471,14 +472,14 @@ __global__ void __launch_bounds__(256) k_train_apply(const ApplyParams p) {
     float w = p.blob[i];
     if (p.optimizer == 0) {
         float m = p.m[i], v = p.v[i];
-        m = m + (g - m) * 0.1f;
+        m = m + (g - m) * p.one_minus_momentum;
         v = v * 0.999f + 0.001f * g * g;
         const float denom = __builtin_sqrtf(v) * p.inv_sqrt_bc2 + 1e-8f;
         w = w - p.lr_over_bc1 * (m / denom);
         p.m[i] = m;
         p.v[i] = v;
     } else {
-        const float buf = p.step == 1 ? g : 0.9f * p.m[i] + g;
+        const float buf = p.step == 1 ? g : p.momentum * p.m[i] + g;
         p.m[i] = buf;
         w = w - p.lr * buf;
     }

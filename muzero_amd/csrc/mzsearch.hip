@@ -746,6 +746,7 @@ struct mzs_handle {
     double* wgrad_partial_dev = nullptr;
     LstmTrainParams lstm_train;    /* 'lstm_model': tape layout and descriptor tables of mzs_train_create */
     int loss_value = MZS_LOSS_CE, loss_reward = MZS_LOSS_CE; /* mzs_train_set_loss */
+    double momentum = 0.9;                                   /* mzs_train_set_momentum */
     size_t w_floats = 0;
     bool have_weights = false;
     int n_nodes_max = 0;
@@ -2114,6 +2115,13 @@ int mzs_train_set_loss(mzs_handle* h, int32_t value_criterion, int32_t reward_cr
     return MZS_OK;
 }
 
+int mzs_train_set_momentum(mzs_handle* h, double momentum) {
+    if (!h) return fail(MZS_E_ARG, "null handle");
+    if (!(momentum >= 0.0 && momentum < 1.0)) return fail(MZS_E_ARG, "momentum must be in [0, 1)");
+    h->momentum = momentum;
+    return MZS_OK;
+}
+
 int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, double lr, void* stream) {
     if (!h || !grad_dev) return fail(MZS_E_ARG, "null argument");
     if (!h->tape_dev) return fail(MZS_E_STATE, "mzs_train_create has not been called");
@@ -2132,7 +2140,9 @@ int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, dou
     p.n = (int)mzs_blob_total(&h->cfg.dims);
     p.optimizer = optimizer;
     p.step = h->train_step;
-    const double bc1 = 1.0 - std::pow(0.9, h->train_step), bc2 = 1.0 - std::pow(0.999, h->train_step);
+    const double bc1 = 1.0 - std::pow(h->momentum, h->train_step), bc2 = 1.0 - std::pow(0.999, h->train_step);
+    p.momentum = (float)h->momentum;
+    p.one_minus_momentum = (float)(1.0 - h->momentum);
     p.lr_over_bc1 = (float)(lr / bc1);
     p.inv_sqrt_bc2 = (float)(1.0 / std::sqrt(bc2));
     p.lr = (float)lr;

@@ -23,7 +23,34 @@ import torch
 from . import _lib
 
 OPTIMIZERS = {"adam": _lib.OPT_ADAM, "sgd": _lib.OPT_SGD}
-SCHEDULERS = (None, "none", "steplr", "cosineannealinglr", "cosineannealinglrwarmrestarts")
+SCHEDULERS = (None, "none", "steplr", "cosineannealinglr", "cosineannealinglrwarmrestarts", "onecyclelr")
+
+
+def _one_cycle(max_lr, total_steps, step):
+    """torch.optim.lr_scheduler.OneCycleLR(max_lr, total_steps) at step_num = step: (lr, momentum).
+    Defaults: pct_start 0.3, cosine annealing, div_factor 25, final_div_factor 1e4, momentum cycled
+    0.95 -> 0.85 -> 0.95 (Adam: beta1), two phases."""
+    total = int(total_steps)
+    if step >= total:
+        raise ValueError(f"Tried to step {step + 1} times. The specified number of total steps is {total}")
+    initial, base_m, max_m = max_lr / 25.0, 0.85, 0.95
+    phases = ((0.3 * total - 1.0, initial, max_lr, max_m, base_m),
+              (total - 1.0, max_lr, initial / 1e4, base_m, max_m))
+    anneal = lambda a, b, pct: b + (a - b) / 2.0 * (math.cos(math.pi * pct) + 1.0)  # noqa: E731
+    start = 0.0
+    for i, (end, lr0, lr1, m0, m1) in enumerate(phases):
+        if step <= end or i == len(phases) - 1:
+            pct = (step - start) / (end - start)
+            return anneal(lr0, lr1, pct), anneal(m0, m1, pct)
+        start = end
+
+
+def scheduled_momentum(scheduler, num_of_epoch, count):
+    """Adam beta1 / SGD momentum the reference's optimizer holds when train() number `count` runs:
+    0.9 (muzero_model.py:418-421) unless OneCycleLR cycles it (same lag as scheduled_lr)."""
+    if scheduler != "onecyclelr":
+        return 0.9
+    return _one_cycle(1.0, num_of_epoch, max(count - 1, 0))[1]
 
 
 def scheduled_lr(scheduler, base_lr, num_of_epoch, count):
@@ -32,6 +59,8 @@ def scheduled_lr(scheduler, base_lr, num_of_epoch, count):
     The reference calls `scheduler.step(epoch=self.count)` AFTER `optimizer.step()` and before
     `count += 1` (muzero_model.py:764-786), which sets the closed-form value for epoch = count;
     so step 0 runs at the base rate and step i > 0 at closed_form(i - 1)."""
+    if scheduler == "onecyclelr":                  # OneCycleLR(max_lr=lr, total_steps=num_of_epoch): the constructor
+        return _one_cycle(float(base_lr), num_of_epoch, max(count - 1, 0))[0]   # already sets the rate of step 0
     if scheduler in (None, "none") or count == 0:
         return float(base_lr)
     e = count - 1
@@ -42,8 +71,7 @@ def scheduled_lr(scheduler, base_lr, num_of_epoch, count):
     if scheduler == "cosineannealinglrwarmrestarts":  # CosineAnnealingWarmRestarts(T_0=num_of_epoch)
         t0 = int(num_of_epoch)
         return float(base_lr) * (1.0 + math.cos(math.pi * (e % t0) / t0)) / 2.0
-    raise NotImplementedError(f"lr_scheduler={scheduler!r}: OneCycleLR also cycles Adam's beta1 per "
-                              "step, which the fused optimizer kernel does not model")
+    raise NotImplementedError(f"lr_scheduler={scheduler!r}: the reference knows {SCHEDULERS[2:]} (muzero_model.py:424)")
 
 
 def reshape_batch(batches, obs_dim, n_actions, unroll_steps):
@@ -147,6 +175,9 @@ class Trainer:
 
     def apply(self):
         e = self.eng
+        if self.sch == "onecyclelr":
+            _lib.check(self.lib.mzs_train_set_momentum(e.h, scheduled_momentum(self.sch, self.epoch, self.count)),
+                       "mzs_train_set_momentum")
         _lib.check(self.lib.mzs_train_apply(e.h, C.c_void_p(self.grad.data_ptr()), OPTIMIZERS[self.opt],
                                             C.c_double(self.current_lr()), e._stream()), "mzs_train_apply")
         self.count += 1

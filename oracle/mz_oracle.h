@@ -126,6 +126,7 @@ typedef struct mzo_train_batch {
 void mzo_train_set_loss(int value_mode, int reward_mode);
 int mzo_train_grad(const mzs_dims* d, const float* blob, const mzo_train_batch* bt, float* grad,
                    float* loss_terms, double* total_loss, float* priority);
+void mzo_set_momentum(double momentum); /* Adam beta1 / SGD momentum of the following steps (default 0.9) */
 void mzo_adam_step(float* w, float* m, float* v, const float* g, size_t n, int step, double lr);
 void mzo_sgd_step(float* w, float* buf, const float* g, size_t n, int step, double lr);
 

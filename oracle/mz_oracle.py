@@ -243,6 +243,13 @@ def train_grad(d, blob, obs, actions, target_value, target_reward, target_policy
     return dict(grad=grad, loss_terms=terms, total_loss=total.value, priority=prio)
 
 
+def set_momentum(momentum=0.9):
+    """Adam's beta1 / SGD's momentum for the following steps (OneCycleLR cycles it)."""
+    f = lib().mzo_set_momentum
+    f.restype = None
+    f(C.c_double(momentum))
+
+
 def adam_step(w, m, v, g, step, lr):
     f = lib().mzo_adam_step
     f.restype = None

@@ -583,8 +583,13 @@ int mzo_train_grad(const mzs_dims* d, const float* blob, const mzo_train_batch* 
 }
 
 /* torch.optim.Adam (betas 0.9 / 0.999, eps 1e-8, no weight decay) — step t >= 1 */
+/* Adam's beta1 / SGD's momentum for the following steps: 0.9 unless OneCycleLR cycles it
+ * (torch.optim.lr_scheduler.OneCycleLR, cycle_momentum: muzero_model.py:433); process-wide state */
+static double g_momentum = 0.9;
+void mzo_set_momentum(double momentum) { g_momentum = momentum; }
+
 void mzo_adam_step(float* w, float* m, float* v, const float* g, size_t n, int step, double lr) {
-    const double b1 = 0.9, b2 = 0.999, eps = 1e-8;
+    const double b1 = g_momentum, b2 = 0.999, eps = 1e-8;
     const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
     const double step_size = lr / bc1, bc2s = sqrt(bc2);
     for (size_t i = 0; i < n; ++i) {
@@ -598,7 +603,7 @@ void mzo_adam_step(float* w, float* m, float* v, const float* g, size_t n, int s
 /* torch.optim.SGD(momentum = 0.9): buf = g on the first step */
 void mzo_sgd_step(float* w, float* buf, const float* g, size_t n, int step, double lr) {
     for (size_t i = 0; i < n; ++i) {
-        buf[i] = step == 1 ? g[i] : 0.9f * buf[i] + g[i];
+        buf[i] = step == 1 ? g[i] : (float)g_momentum * buf[i] + g[i];
         w[i] = w[i] - (float)lr * buf[i];
     }
 }

@@ -19,14 +19,14 @@ import make_train_fixtures as mt  # noqa: E402
 mf, mm = mt.mf, mt.mm
 
 
-def make_model(dims, K, lr, loss_type, seed, std=0.3):
+def make_model(dims, K, lr, loss_type, seed, std=0.3, sch=None, opt="adam", epoch=100):
     obs, A, Sd, H, L = dims
     torch.manual_seed(seed)
     mz = mm.Muzero(model_structure="mlp_model", observation_space_dimensions=mf.Box((obs,)),
                    action_space_dimensions=mf.Discrete(A), state_space_dimensions=Sd,
                    hidden_layer_dimensions=H, number_of_hidden_layer=L, k_hypothetical_steps=K,
-                   learning_rate=lr, optimizer="adam", lr_scheduler=None, loss_type=loss_type,
-                   num_of_epoch=100, device="cpu")
+                   learning_rate=lr, optimizer=opt, lr_scheduler=sch, loss_type=loss_type,
+                   num_of_epoch=epoch, device="cpu")
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():
         for net in (mz.representation_function, mz.dynamics_function, mz.prediction_function):
@@ -55,6 +55,12 @@ def main():
         else:
             mt.synth_batch = synth
         mt.run_case(f"train_loss_{lt}_K3_B24.npz", mz, dims, 3, 24, 2, 31 + i, 0.25, "vector", hyper)
+    # OneCycleLR (muzero_model.py:433): the rate AND Adam's beta1 / SGD's momentum change every step
+    mt.synth_batch = synth
+    for opt, lr in (("adam", 0.01), ("sgd", 0.05)):
+        hyper = dict(lr=lr, optimizer=opt, scheduler="onecyclelr", epoch=12)
+        mz = make_model(dims, 3, lr, "general", seed=41, sch="onecyclelr", opt=opt, epoch=12)
+        mt.run_case(f"train_onecycle_{opt}_K3_B24.npz", mz, dims, 3, 24, 6, 51, 0.25, "vector", hyper)
 
 
 if __name__ == "__main__":

@@ -60,12 +60,17 @@ def test_train_step_vs_oracle_and_reference(fname):
         else:
             m, v = test_train_step_vs_oracle_and_reference._m, test_train_step_vs_oracle_and_reference._v
         w = blob_before.copy()
+        from muzero_amd.train import scheduled_momentum
+        mzo.set_momentum(scheduled_momentum(tr.sch, tr.epoch, s))   # OneCycleLR cycles it, else 0.9
         if str(fx["optimizer"]) == "adam":
             mzo.adam_step(w, m, v, got["grad"], s + 1, lr)
         else:
             mzo.sgd_step(w, m, got["grad"], s + 1, lr)
+        mzo.set_momentum(0.9)
         test_train_step_vs_oracle_and_reference._m, test_train_step_vs_oracle_and_reference._v = m, v
         assert np.abs(blob_after - w).max() <= 1e-6 + 1e-5 * lr
+        if str(fx["scheduler"]) == "onecyclelr":                   # all six steps against the reference's weights
+            assert np.abs(blob_after - fx[f"s{s}_blob"]).max() <= (s + 1) * 2e-3 * float(fx["lr"]) + 1e-6
     eng.close()
 
 

@@ -13,7 +13,9 @@ LSTM_TRAIN_FIXTURES = ["train_lstmA_K5_B128.npz", "train_lstmB_K3_B32.npz", "tra
 # the reference's other loss types (tests/golden/make_loss_fixtures.py): KL / KL, MSE / zero, MSE / MSE
 LOSS_TRAIN_FIXTURES = ["train_loss_general_kkc_K3_B24.npz", "train_loss_game_K3_B24.npz",
                        "train_loss_game_mmc_K3_B24.npz"]
-TRAIN_FIXTURES = MLP_TRAIN_FIXTURES + LSTM_TRAIN_FIXTURES + LOSS_TRAIN_FIXTURES
+# OneCycleLR (muzero_model.py:433): rate and Adam beta1 / SGD momentum change every step; six steps of twelve
+ONECYCLE_FIXTURES = ["train_onecycle_adam_K3_B24.npz", "train_onecycle_sgd_K3_B24.npz"]
+TRAIN_FIXTURES = MLP_TRAIN_FIXTURES + LSTM_TRAIN_FIXTURES + LOSS_TRAIN_FIXTURES + ONECYCLE_FIXTURES
 
 
 def loss_type_of(fx):
@@ -62,7 +64,7 @@ def check_against_fixture(fx, s, out, blob_after=None, lr=None):
 
 @pytest.mark.parametrize("fname", TRAIN_FIXTURES)
 def test_train_oracle_matches_reference(fname):
-    from muzero_amd.train import scheduled_lr
+    from muzero_amd.train import scheduled_lr, scheduled_momentum
     from oracle import mz_oracle as mzo
     fx = load_golden(fname)
     d = mzo.dims(*fx["dims"])
@@ -72,6 +74,7 @@ def test_train_oracle_matches_reference(fname):
     for s in range(int(fx["n_steps"])):
         out = mzo.train_grad(d, blob, **step_inputs(fx, s), loss_type=loss_type_of(fx))
         lr = scheduled_lr(sch, float(fx["lr"]), int(fx["epoch"]), s)
+        mzo.set_momentum(scheduled_momentum(sch, int(fx["epoch"]), s))
         if opt == "adam":
             mzo.adam_step(blob, m, v, out["grad"], s + 1, lr)
         else:
@@ -81,6 +84,7 @@ def test_train_oracle_matches_reference(fname):
         assert abs(scheduled_lr(sch, float(fx["lr"]), int(fx["epoch"]), s + 1) - float(fx[f"s{s}_lr_next"])) \
             <= 1e-12
         blob = fx[f"s{s}_blob"].copy()      # re-anchor: later steps test the step, not the drift
+    mzo.set_momentum(0.9)
 
 
 def test_data_parallel_shards_sum_to_the_full_batch():
@@ -132,5 +136,15 @@ def test_scheduled_lr_closed_forms():
     assert abs(scheduled_lr("steplr", 1.0, 10, 3) - 0.99 ** 2) < 1e-15
     assert scheduled_lr(None, 0.3, 10, 7) == 0.3
     assert abs(scheduled_lr("cosineannealinglrwarmrestarts", 1.0, 10, 12) - (1 + math.cos(math.pi * 0.1)) / 2) < 1e-12
+    # OneCycleLR(max_lr=0.01, total_steps=50): values read off the reference's optimizer (lr, beta1) after
+    # train() calls 1..4 (tests/golden/make_loss_fixtures.py's recipe)
+    from muzero_amd.train import scheduled_momentum
+    for count, lr, b1 in ((0, 0.0004, 0.95), (1, 0.0003999999999999993, 0.95), (2, 0.0005203460215272467, 0.9487463956090911),
+                          (3, 0.0008753494340683881, 0.945048443395121), (4, 0.0014472088841534555, 0.9390915741234015)):
+        assert abs(scheduled_lr("onecyclelr", 0.01, 50, count) - lr) < 1e-15
+        assert abs(scheduled_momentum("onecyclelr", 50, count) - b1) < 1e-15
+    assert scheduled_momentum("steplr", 50, 3) == 0.9
+    with pytest.raises(ValueError):
+        scheduled_lr("onecyclelr", 0.01, 5, 7)            # torch raises past total_steps
     with pytest.raises(NotImplementedError):
-        scheduled_lr("onecyclelr", 0.1, 10, 1)
+        scheduled_lr("exponentiallr", 0.1, 10, 1)
