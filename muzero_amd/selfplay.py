@@ -503,6 +503,8 @@ def play_until(engine, arena, done_upto, num_simulations, temperature, check_eve
     for the next call).  In the final drain (queue empty) one chunk at a time is issued, so that no
     search runs on an arena that has nothing left to play."""
     S = int(num_simulations)
+    if check_every * depth > 256:
+        raise ValueError("check_every * depth must stay within the 256 status entries the arena keeps")
     moves, st, ev = 0, None, None
     limit = max_moves if max_moves is not None else (done_upto + arena.G) * arena.T
     draining = False
