@@ -178,7 +178,7 @@ __device__ __forceinline__ void pair_trunk(WideStream& st, const float* bias_hal
             const float4 c = *reinterpret_cast<const float4*>(onehot_half + act[4 * s + q.c] * 128 + q.n0);
             acc[s] = f32x4{acc[s][0] + c.x, acc[s][1] + c.y, acc[s][2] + c.z, acc[s][3] + c.w};
         }
-        store4(out + (4 * s + q.c) * kPairTStride + 64 * u + q.n0, elu4<false>(acc[s]));
+        store4(out + (4 * s + q.c) * kPairTStride + 64 * u + q.n0, elu4<true>(acc[s]));
     }
 }
 
@@ -211,7 +211,7 @@ __device__ __forceinline__ void pair_model(WideStream& st, const Model& m, const
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             if (u == 0) { /* reward head */
-                const float yr = wide_support_mean(wide_softmax(a[s], vd), vd, q, SD);
+                const float yr = wide_support_mean(wide_softmax<true>(a[s], vd), vd, q, SD);
                 if (q.b == 0) P.rew[4 * s + q.c] = yr;
             } else { /* next hidden state: P.xin is free (its last readers passed the first barrier) */
                 const f32x4 y = wide_scale_to_bound(a[s], vd);
@@ -239,10 +239,10 @@ __device__ __forceinline__ void pair_model(WideStream& st, const Model& m, const
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
         if (u == 0) { /* policy head */
-            const f32x4 pr = wide_softmax(a[s], wide_valid(q, NA));
+            const f32x4 pr = wide_softmax<true>(a[s], wide_valid(q, NA));
             if (q.b == 0) store4(P.pri + 4 * (4 * s + q.c), pr);
         } else { /* value head */
-            const float yv = wide_support_mean(wide_softmax(a[s], vd), vd, q, SD);
+            const float yv = wide_support_mean(wide_softmax<true>(a[s], vd), vd, q, SD);
             if (q.b == 0) P.val[4 * s + q.c] = yv;
         }
     }
