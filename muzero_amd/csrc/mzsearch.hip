@@ -1143,8 +1143,8 @@ SearchPlan plan_search(const mzs_handle* h, int S, int n_games) {
             pl.kernel = k2;
             pl.ql = qg;
             pl.wpb = 4;
-            std::snprintf(pl.name, sizeof pl.name, "k_search_quad<%d,%d,%d,false,false,true,%s2 waves/SIMD>",
-                          d.state_dim, A, d.hidden_dim, d.precision == MZS_PRECISION_BF16 ? "bf16," : "");
+            std::snprintf(pl.name, sizeof pl.name, "k_search_quad<%d,%d,%d,false,%s,true,%s2 waves/SIMD>", d.state_dim, A,
+                          d.hidden_dim, d.n_mid_layers ? "true" : "false", d.precision == MZS_PRECISION_BF16 ? "bf16," : "");
             return pl;
         }
     }

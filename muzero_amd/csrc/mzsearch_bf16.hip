@@ -23,13 +23,13 @@ static quad_kernel_t pick_quad_kernel_b16_t(const mzs_dims& d) {
     }
     return nullptr;
 }
-/* the same kernels compiled for two wavefronts per SIMD (hidden states in the global array, no tied
- * mid layers: those need the whole register file) */
+/* the same kernels compiled for two wavefronts per SIMD (hidden states in the global array) */
 static quad_kernel_t pick_quad_kernel_b16_occ2(const mzs_dims& d) {
-    if (d.obs_dim > 64 || d.model_kind != MZS_MODEL_MLP || d.n_mid_layers != 0) return nullptr;
+    if (d.obs_dim > 64 || d.model_kind != MZS_MODEL_MLP) return nullptr;
+    const bool mid = d.n_mid_layers != 0; /* packed, even the tied mid layers fit 256 registers (~12 reloads per simulation) */
     if (d.state_dim == 31 && d.hidden_dim == 64) {
-        if (d.n_actions == 2) return k_search_quad<31, 2, 64, false, false, true, true, 2>;
-        if (d.n_actions == 4) return k_search_quad<31, 4, 64, false, false, true, true, 2>;
+        if (d.n_actions == 2) return mid ? k_search_quad<31, 2, 64, false, true, true, true, 2> : k_search_quad<31, 2, 64, false, false, true, true, 2>;
+        if (d.n_actions == 4) return mid ? k_search_quad<31, 4, 64, false, true, true, true, 2> : k_search_quad<31, 4, 64, false, false, true, true, 2>;
     }
     return nullptr;
 }

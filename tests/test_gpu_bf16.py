@@ -133,7 +133,8 @@ def test_bf16_full_size_4096_games_vs_oracle():
     eng.close()
 
 
-@pytest.mark.parametrize("shape,S", [((4, 2, 31, 64, 0), 50), ((8, 4, 31, 64, 0), 24)])
+@pytest.mark.parametrize("shape,S", [((4, 2, 31, 64, 0), 50), ((8, 4, 31, 64, 0), 24), ((4, 2, 31, 64, 4), 30),
+                                     ((8, 4, 31, 64, 1), 20)])
 def test_bf16_two_waves_per_simd_vs_oracle(shape, S):
     """More than sixteen games per CU: mzs_search takes the bf16 kernel compiled for two wavefronts per
     SIMD (two blocks share a CU; a few registers of the prologue live in scratch).  Ragged game count,
