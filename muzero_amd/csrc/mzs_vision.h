@@ -180,17 +180,18 @@ __device__ __forceinline__ void vis_avgpool(const float* in, int C, int Si, floa
     wave_sync();
 }
 
-/* y = [relu](b + W x), W [nout][nin] in the blob, contract "dot" (even / odd chains) */
-__device__ __forceinline__ void vis_linear(const float* __restrict__ W, const float* __restrict__ b, const float* x,
+/* y = [relu](b + W x), contract "dot" (even / odd chains); Wt = W^T [nin][nout] (the transposed copy
+ * mzs_set_weights makes: lanes read neighbouring addresses), sixteen rows in flight ahead of the chains */
+__device__ __forceinline__ void vis_linear(const float* __restrict__ Wt, const float* __restrict__ b, const float* x,
                                            int nout, int nin, bool relu, float* y, int lane) {
     for (int j = lane; j < nout; j += kWave) {
-        const float* __restrict__ w = W + (size_t)j * nin;
+        const float* __restrict__ w = Wt + j;
         float e = b[j], o = 0.0f;
         int k = 0;
-        for (; k + 15 < nin; k += 16) { /* sixteen weights in flight ahead of the chains (load latency) */
+        for (; k + 15 < nin; k += 16) {
             float wv[16];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) wv[u] = w[k + u];
+            for (int u = 0; u < 16; ++u) wv[u] = w[(size_t)(k + u) * nout];
 #pragma unroll
             for (int u = 0; u < 16; u += 2) {
                 e = mzs_fma(wv[u], x[k + u], e);
@@ -198,10 +199,10 @@ __device__ __forceinline__ void vis_linear(const float* __restrict__ W, const fl
             }
         }
         for (; k + 1 < nin; k += 2) {
-            e = mzs_fma(w[k], x[k], e);
-            o = mzs_fma(w[k + 1], x[k + 1], o);
+            e = mzs_fma(w[(size_t)k * nout], x[k], e);
+            o = mzs_fma(w[(size_t)(k + 1) * nout], x[k + 1], o);
         }
-        if (k < nin) e = mzs_fma(w[k], x[k], e);
+        if (k < nin) e = mzs_fma(w[(size_t)k * nout], x[k], e);
         const float v = e + o;
         y[j] = relu && !(v > 0.0f) ? 0.0f : v;
     }
@@ -230,15 +231,15 @@ __device__ __forceinline__ void vis_head_mlp(const Model& m, const float* __rest
         t1[idx] = acc;
     }
     wave_sync();
-    vis_linear(blob + fc.in_w, blob + fc.in_b, t1, m.H, kVisHidden, true, t2, lane);
+    vis_linear(m.w + fc.in_w, blob + fc.in_b, t1, m.H, kVisHidden, true, t2, lane);
     float *a = t2, *bb = t1;
     for (int l = 0; l < m.L; ++l) {
-        vis_linear(blob + fc.mid_w, blob + fc.mid_b, a, m.H, m.H, true, bb, lane);
+        vis_linear(m.w + fc.mid_w, blob + fc.mid_b, a, m.H, m.H, true, bb, lane);
         float* t = a;
         a = bb;
         bb = t;
     }
-    vis_linear(blob + fc.out_w, blob + fc.out_b, a, fc.n_out, m.H, false, logits, lane);
+    vis_linear(m.w + fc.out_w, blob + fc.out_b, a, fc.n_out, m.H, false, logits, lane);
 }
 
 __device__ __forceinline__ mzs_vision_offsets vis_offsets(const Model& m) {

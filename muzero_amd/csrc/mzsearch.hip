@@ -1313,6 +1313,7 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     StoreBuilder sb;
     describe_model(d, &h->model, &sb);
     h->w_floats = sb.data.size();
+    if (d.model_kind == MZS_MODEL_VISION) h->w_floats = mzs_blob_total(&d); /* the blob with its Linear weights transposed */
     h->n_nodes_max = mzs_nodes_per_game(d.n_actions, cfg->max_simulations);
     h->lds = make_lds_layout(h->model, h->n_nodes_max, cfg->max_simulations);
     if (waves_per_block(h->lds) == 0) {
@@ -1398,8 +1399,24 @@ int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats) {
     HIP_TRY(hipMemcpy(host.data(), blob, n_floats * sizeof(float), hipMemcpyDefault));
     const float* B = host.data();
     const int H = d.hidden_dim, Sd = d.state_dim, A = d.n_actions, ob = d.obs_dim;
-    if (d.model_kind == MZS_MODEL_VISION) { /* the kernels read the blob in place */
+    if (d.model_kind == MZS_MODEL_VISION) {
+        /* convolutions, batchnorms and biases are read from the blob in place; the Linear layers of the three
+         * head MLPs from a second copy in which every weight matrix [n_out][n_in] is stored transposed (same
+         * offsets): lane j of a wave then reads W^T[k][j] — neighbouring addresses — where the torch layout
+         * would make the 64 lanes of a load touch 64 cache lines */
         HIP_TRY(hipMemcpy(h->blob_dev, B, n_floats * sizeof(float), hipMemcpyHostToDevice));
+        std::vector<float> t(host);
+        const mzs_vision_offsets vo = mzs_vision_layout(&d);
+        const auto transpose = [&](size_t off, int n_out, int n_in) {
+            for (int j = 0; j < n_out; ++j)
+                for (int k = 0; k < n_in; ++k) t[off + (size_t)k * n_out + j] = B[off + (size_t)j * n_in + k];
+        };
+        for (const mzs_vis_mlp* fc : {&vo.d_fc, &vo.p_v, &vo.p_p}) {
+            transpose(fc->in_w, H, MZS_VIS_HIDDEN);
+            if (d.n_mid_layers > 0) transpose(fc->mid_w, H, H);
+            transpose(fc->out_w, fc->n_out, H);
+        }
+        HIP_TRY(hipMemcpy(h->w_dev, t.data(), n_floats * sizeof(float), hipMemcpyHostToDevice));
         h->have_weights = true;
         return MZS_OK;
     }
