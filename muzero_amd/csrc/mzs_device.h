@@ -78,6 +78,7 @@ struct WaveLds {
     float* xa;            /* trunk activations, ping                            */
     float* xb;            /* trunk activations, pong                            */
     float* ob;            /* head outputs (logit segments)                      */
+    float* vc;            /* vision model: cached convolution / batchnorm parameters */
 };
 
 __device__ __forceinline__ void wave_sync() {

@@ -26,7 +26,7 @@ namespace mzs {
 
 /* byte offsets inside one wave's LDS slice */
 struct LdsLayout {
-    int off_cb, off_path, off_xh, off_xa, off_xb, off_ob, bytes;
+    int off_cb, off_path, off_xh, off_xa, off_xb, off_ob, off_vc, bytes;
 };
 
 struct TreeArrays {

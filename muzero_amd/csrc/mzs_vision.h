@@ -15,8 +15,9 @@
  *
  * Channel counts are 1..4 and the maps 49 x 49 down to 7 x 7: HBM- and latency-bound work with K =
  * 9..36 per output, nothing for MFMA.  Lanes own output pixels; every map lives in the wave's LDS
- * slice (three buffers of 49 x 49 floats for the representation, 7 x 7 x 4 afterwards), the weights
- * (a few hundred floats per convolution) are read from the blob through the scalar/L1 caches.
+ * slice (three buffers of 49 x 49 floats for the representation, 7 x 7 x 4 afterwards), and so does a copy
+ * of every convolution's and batchnorm's parameters (vis_cache_load, once per kernel); the Linear layers
+ * of the head MLPs stream their weights from the transposed copy in global memory.
  */
 #ifndef MZS_VISION_H
 #define MZS_VISION_H
@@ -27,133 +28,120 @@ constexpr int kVisC = MZS_VIS_C, kVisHidden = MZS_VIS_HIDDEN, kVisPix = MZS_VIS_
 constexpr int kVisBuf = 2432;  /* floats of one scratch map: >= 49 * 49, >= 3 * 25 * 25 */
 constexpr int kVisXh = 208;    /* hidden state (147) + action plane (49), rounded */
 
-/* out [Co][So][So] = conv3x3(in [Ci][Si][Si]), stride s, padding 1, no bias; in: LDS or global.
- * One output per lane and pass; its Ci x 9 taps are all fetched (inputs and weights; a padding tap
- * reads a clamped address and is marked) BEFORE the fma chain that consumes them in (ci, ky, kx)
- * order, padding taps skipped by a select — the wave is alone on its SIMD, so a chain that waits for
- * a load per tap (as the plain loop did) is bound by 27-36 load latencies per output. */
+/* The small parameters (every convolution and batchnorm: blob ranges [0, d_fc.in_w) and [p_res.conv_a,
+ * p_v.in_w), 826 + 198 floats at C = 3) are copied once per kernel into the wave's LDS slice (L.vc): a
+ * simulation reads them ~35 times, and from the blob every read was a trip to L2 (~0.4 us) that the wave,
+ * alone on its SIMD, waited out.  Blob offsets of the first range index the cache as they are, those of
+ * the second less vis_cache_delta. */
+constexpr int kVisCache = 1024; /* floats; mzs_create checks that the two ranges fit */
+
+/* what to subtract from a blob offset of the second range to index the cache */
+__device__ __forceinline__ size_t vis_cache_delta(const mzs_vision_offsets& o) { return o.p_res.conv_a - o.d_fc.in_w; }
+
+__device__ __forceinline__ void vis_cache_load(const float* __restrict__ blob, const mzs_vision_offsets& o, float* vc,
+                                               int lane) {
+    const int n1 = (int)o.d_fc.in_w, n2 = (int)(o.p_v.in_w - o.p_res.conv_a);
+    for (int i = lane; i < n1; i += kWave) vc[i] = blob[i];
+    for (int i = lane; i < n2; i += kWave) vc[n1 + i] = blob[o.p_res.conv_a + i];
+    wave_sync();
+}
+
+/* out [Co][So][So] = conv3x3(in [Ci][Si][Si]), stride s, padding 1, no bias; in: LDS or global; w: the
+ * cached weights.  Output channels in turn (their Ci x 9 weights in registers, the same for every lane),
+ * one output pixel per lane and pass; the pass's Ci x 9 inputs are all fetched (a padding tap reads a
+ * clamped address and is marked) BEFORE the fma chain that consumes them in (ci, ky, kx) order, padding
+ * taps skipped by a select — the wave is alone on its SIMD, so a chain that waits for a load per tap (as
+ * the plain loop did) is bound by 27-36 load latencies per output. */
 template <int CI>
-__device__ __forceinline__ void vis_conv3_t(const float* __restrict__ w, const float* in, int Si, int Co, int s,
-                                            float* out, int lane) {
+__device__ __forceinline__ void vis_conv3_t(const float* w, const float* in, int Si, int Co, int s, float* out,
+                                            int lane) {
     const int So = (Si - 1) / s + 1, n = So * So;
-    for (int idx0 = 0; idx0 < Co * n; idx0 += kWave) {
-        const int idx = idx0 + lane;
-        const bool live = idx < Co * n;
-        const int id = live ? idx : 0;
-        const int co = id / n, r = id - co * n, oy = r / So, ox = r - oy * So;
-        float xv[CI * 9], wv[CI * 9];
-        bool ok[9];
-        int off[9];
+    const float inv_so = 1.0f / (float)So; /* r / So below: r < 2401, So <= 49, exact with the half offset */
+    for (int co = 0; co < Co; ++co) {
+        float wv[CI * 9];
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
+        for (int j = 0; j < CI * 9; ++j) wv[j] = w[co * CI * 9 + j];
+        for (int r0 = 0; r0 < n; r0 += kWave) {
+            const bool live = r0 + lane < n;
+            const int r = live ? r0 + lane : 0;
+            const int oy = (int)(((float)r + 0.5f) * inv_so), ox = r - oy * So;
+            float xv[CI * 9];
+            bool ok[9];
+            int off[9];
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                const int iy = oy * s + ky - 1, ix = ox * s + kx - 1;
-                const bool v = iy >= 0 && iy < Si && ix >= 0 && ix < Si;
-                ok[ky * 3 + kx] = v;
-                off[ky * 3 + kx] = v ? iy * Si + ix : 0;
+            for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int iy = oy * s + ky - 1, ix = ox * s + kx - 1;
+                    const bool v = iy >= 0 && iy < Si && ix >= 0 && ix < Si;
+                    ok[ky * 3 + kx] = v;
+                    off[ky * 3 + kx] = v ? iy * Si + ix : 0;
+                }
             }
-        }
 #pragma unroll
-        for (int ci = 0; ci < CI; ++ci) {
-            const float* __restrict__ wk = w + (co * CI + ci) * 9;
-            const float* ip = in + (size_t)ci * Si * Si;
+            for (int ci = 0; ci < CI; ++ci) {
+                const float* ip = in + (size_t)ci * Si * Si;
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                wv[ci * 9 + t] = wk[t];
-                xv[ci * 9 + t] = ip[off[t]];
+                for (int t = 0; t < 9; ++t) xv[ci * 9 + t] = ip[off[t]];
             }
-        }
-        float acc = 0.0f;
+            float acc = 0.0f;
 #pragma unroll
-        for (int ci = 0; ci < CI; ++ci) {
+            for (int ci = 0; ci < CI; ++ci) {
 #pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float a2 = mzs_fma(wv[ci * 9 + t], xv[ci * 9 + t], acc);
-                acc = ok[t] ? a2 : acc;
+                for (int t = 0; t < 9; ++t) {
+                    const float a2 = mzs_fma(wv[ci * 9 + t], xv[ci * 9 + t], acc);
+                    acc = ok[t] ? a2 : acc;
+                }
             }
+            if (live) out[co * n + r] = acc;
         }
-        if (live) out[idx] = acc;
     }
     wave_sync();
 }
 
-__device__ __forceinline__ void vis_conv3(const float* __restrict__ w, const float* in, int Ci, int Si, int Co, int s,
-                                          float* out, int lane) {
+__device__ __forceinline__ void vis_conv3(const float* w, const float* in, int Ci, int Si, int Co, int s, float* out,
+                                          int lane) {
     switch (Ci) { /* the model's channel counts: C / 2, C, C + 1 with C = MZS_VIS_C */
         case 1: vis_conv3_t<1>(w, in, Si, Co, s, out, lane); return;
         case 2: vis_conv3_t<2>(w, in, Si, Co, s, out, lane); return;
         case 3: vis_conv3_t<3>(w, in, Si, Co, s, out, lane); return;
-        case 4: vis_conv3_t<4>(w, in, Si, Co, s, out, lane); return;
-        default: break;
+        default: vis_conv3_t<4>(w, in, Si, Co, s, out, lane); return;
     }
-    const int So = (Si - 1) / s + 1, n = So * So;
-    for (int idx = lane; idx < Co * n; idx += kWave) {
-        const int co = idx / n, r = idx - co * n, oy = r / So, ox = r - oy * So;
-        float acc = 0.0f;
-        for (int ci = 0; ci < Ci; ++ci) {
-            const float* __restrict__ wk = w + (co * Ci + ci) * 9;
-            const float* ip = in + (size_t)ci * Si * Si;
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int iy = oy * s + ky - 1;
-                if (iy < 0 || iy >= Si) continue;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int ix = ox * s + kx - 1;
-                    if (ix < 0 || ix >= Si) continue;
-                    acc = mzs_fma(wk[ky * 3 + kx], ip[iy * Si + ix], acc);
-                }
-            }
+}
+
+/* out = relu(batchnorm(in)) on [C][n], eval mode; cw: the cached parameters.  gamma / sqrt(var + eps)
+ * once per channel — the same value as once per element */
+__device__ __forceinline__ void vis_bn_relu(const float* cw, const mzs_vis_bn& bn, const float* in, int C, int n,
+                                            float* out, int lane) {
+    for (int c = 0; c < C; ++c) {
+        const float g = cw[bn.w + c], var = cw[bn.var + c], mu = cw[bn.mean + c], be = cw[bn.b + c];
+        const float iv = g / __builtin_sqrtf(var + 1e-5f);
+        for (int i = lane; i < n; i += kWave) {
+            const float y = mzs_fma(in[c * n + i] - mu, iv, be);
+            out[c * n + i] = y > 0.0f ? y : 0.0f;
         }
-        out[idx] = acc;
     }
     wave_sync();
 }
 
-/* out = relu(batchnorm(in)) on [C][n], eval mode */
-__device__ __forceinline__ void vis_bn_relu(const float* __restrict__ blob, const mzs_vis_bn& bn, const float* in, int C,
-                                            int n, float* out, int lane) {
-    /* the per-channel constants once per call (C <= kVisC + 1 channels, their loads in flight together),
-     * not once per element: gamma / sqrt(var + eps) is the same value either way */
-    constexpr int CM = kVisC + 1;
-    float inv[CM], mu[CM], be[CM];
-#pragma unroll
-    for (int c = 0; c < CM; ++c) {
-        const int cc = c < C ? c : 0;
-        inv[c] = blob[bn.w + cc], mu[c] = blob[bn.var + cc], be[c] = blob[bn.b + cc];
+/* x += conv_a(R(conv_b(R(conv_a(R(x)))))), R = relu(batchnorm(.)); x [C][S][S]; t1, t2 scratch.  The block's
+ * parameters sit at `base` of the cache in mzs_vis_res_layout's order (conv_a, conv_b, batchnorm): plain
+ * scalars — offsets selected out of the layout structs ended up as indexed loads from scratch memory */
+__device__ __forceinline__ void vis_res_block(const float* blob, size_t base, int C, float* x, int S, float* t1,
+                                              float* t2, int lane) {
+    const int n = S * S;
+    const size_t cc9 = (size_t)C * C * 9;
+    mzs_vis_bn bn;
+    bn.w = base + 2 * cc9, bn.b = bn.w + C, bn.mean = bn.w + 2 * C, bn.var = bn.w + 3 * C;
+    /* one copy of the batchnorm + convolution code per block (a loop, not three inlined stages): the
+     * simulation loop has to fit the instruction cache */
+    const float* src = x;
+#pragma nounroll
+    for (int i = 0; i < 3; ++i) {
+        vis_bn_relu(blob, bn, src, C, n, t1, lane);
+        vis_conv3(blob + base + (i == 1 ? cc9 : 0), t1, C, S, C, 1, t2, lane);
+        src = t2;
     }
-#pragma unroll
-    for (int c = 0; c < CM; ++c) {
-        const int cc = c < C ? c : 0;
-        inv[c] = inv[c] / __builtin_sqrtf(mu[c] + 1e-5f);
-        mu[c] = blob[bn.mean + cc];
-    }
-    for (int idx = lane; idx < C * n; idx += kWave) {
-        const int c = idx / n;
-        float iv = inv[0], m0 = mu[0], b0 = be[0];
-#pragma unroll
-        for (int k = 1; k < CM; ++k) {
-            iv = c == k ? inv[k] : iv;
-            m0 = c == k ? mu[k] : m0;
-            b0 = c == k ? be[k] : b0;
-        }
-        const float y = mzs_fma(in[idx] - m0, iv, b0);
-        out[idx] = y > 0.0f ? y : 0.0f;
-    }
-    wave_sync();
-}
-
-/* x += conv_a(R(conv_b(R(conv_a(R(x)))))), R = relu(batchnorm(.)); x [C][S][S]; t1, t2 scratch */
-__device__ __forceinline__ void vis_res_block(const float* __restrict__ blob, const mzs_vis_res& r, float* x, int S,
-                                              float* t1, float* t2, int lane) {
-    const int C = r.C, n = S * S;
-    vis_bn_relu(blob, r.bn, x, C, n, t1, lane);
-    vis_conv3(blob + r.conv_a, t1, C, S, C, 1, t2, lane);
-    vis_bn_relu(blob, r.bn, t2, C, n, t1, lane);
-    vis_conv3(blob + r.conv_b, t1, C, S, C, 1, t2, lane);
-    vis_bn_relu(blob, r.bn, t2, C, n, t1, lane);
-    vis_conv3(blob + r.conv_a, t1, C, S, C, 1, t2, lane);
     for (int i = lane; i < C * n; i += kWave) x[i] = t2[i] + x[i];
     wave_sync();
 }
@@ -181,65 +169,96 @@ __device__ __forceinline__ void vis_avgpool(const float* in, int C, int Si, floa
 }
 
 /* y = [relu](b + W x), contract "dot" (even / odd chains); Wt = W^T [nin][nout] (the transposed copy
- * mzs_set_weights makes: lanes read neighbouring addresses), sixteen rows in flight ahead of the chains */
+ * mzs_set_weights makes: lanes read neighbouring addresses).  Sixty-four rows are requested ahead of the
+ * chains that consume them (a trip to L2 per batch: three for the 147-wide layer, one for the others,
+ * where batches of sixteen made ten and four); the last, partial batch reads clamped rows and skips them
+ * by a select. */
 __device__ __forceinline__ void vis_linear(const float* __restrict__ Wt, const float* __restrict__ b, const float* x,
                                            int nout, int nin, bool relu, float* y, int lane) {
+    constexpr int NB = 64, NT = 32;
     for (int j = lane; j < nout; j += kWave) {
         const float* __restrict__ w = Wt + j;
         float e = b[j], o = 0.0f;
         int k = 0;
-        for (; k + 15 < nin; k += 16) {
-            float wv[16];
+        for (; k + NB <= nin; k += NB) {
+            float wv[NB];
+            float4 xq[NB / 4];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) wv[u] = w[(size_t)(k + u) * nout];
+            for (int u = 0; u < NB; ++u) wv[u] = w[(size_t)(k + u) * nout];
 #pragma unroll
-            for (int u = 0; u < 16; u += 2) {
-                e = mzs_fma(wv[u], x[k + u], e);
-                o = mzs_fma(wv[u + 1], x[k + u + 1], o);
+            for (int u = 0; u < NB / 4; ++u) xq[u] = *reinterpret_cast<const float4*>(x + k + 4 * u);
+            __builtin_amdgcn_sched_barrier(0); /* every request of the batch leaves before the chains start */
+#pragma unroll
+            for (int u = 0; u < NB / 4; ++u) {
+                e = mzs_fma(wv[4 * u], xq[u].x, e);
+                o = mzs_fma(wv[4 * u + 1], xq[u].y, o);
+                e = mzs_fma(wv[4 * u + 2], xq[u].z, e);
+                o = mzs_fma(wv[4 * u + 3], xq[u].w, o);
             }
         }
-        for (; k + 1 < nin; k += 2) {
-            e = mzs_fma(w[(size_t)k * nout], x[k], e);
-            o = mzs_fma(w[(size_t)(k + 1) * nout], x[k + 1], o);
+        for (; k < nin; k += NT) { /* k is even here: even rows feed e, odd rows o, as above */
+            float wv[NT], xv[NT];
+#pragma unroll
+            for (int u = 0; u < NT; ++u) {
+                const int kk = k + u < nin ? k + u : nin - 1;
+                wv[u] = w[(size_t)kk * nout], xv[u] = x[kk];
+            }
+#pragma unroll
+            for (int u = 0; u < NT; u += 2) {
+                const float e2 = mzs_fma(wv[u], xv[u], e), o2 = mzs_fma(wv[u + 1], xv[u + 1], o);
+                e = k + u < nin ? e2 : e;
+                o = k + u + 1 < nin ? o2 : o;
+            }
         }
-        if (k < nin) e = mzs_fma(w[(size_t)k * nout], x[k], e);
         const float v = e + o;
         y[j] = relu && !(v > 0.0f) ? 0.0f : v;
     }
     wave_sync();
 }
 
-/* 1x1 convolution (+bias) of x [Ci][49] -> flatten -> Linear, relu, (Linear, relu) x L, Linear: logits */
-__device__ __forceinline__ void vis_head_mlp(const Model& m, const float* __restrict__ blob, size_t conv_w, size_t conv_b,
-                                             int Ci, const mzs_vis_mlp& fc, const float* x, float* logits, float* t1,
-                                             float* t2, int lane) {
-    for (int idx = lane; idx < kVisC * kVisPix; idx += kWave) {
-        const int co = idx / kVisPix, i = idx - co * kVisPix;
-        constexpr int CM = kVisC + 1;
-        float wv[CM], xv[CM]; /* the taps' loads in flight together, then the chain */
+/* 1x1 convolution (+bias) of x [Ci][49] -> flatten -> Linear, relu, (Linear, relu) x L, Linear: logits.
+ * cw: the cached parameters (conv_w, conv_b are blob offsets into them) */
+__device__ __forceinline__ void vis_head_mlp(const Model& m, const float* __restrict__ blob, const float* cw,
+                                             size_t conv_w, size_t conv_b, int Ci, size_t fc_base, int n_out,
+                                             const float* x, float* logits, float* t1, float* t2, int lane) {
+    constexpr int CM = kVisC + 1;
+    for (int co = 0; co < kVisC; ++co) {
+        float wv[CM];
 #pragma unroll
-        for (int ci = 0; ci < CM; ++ci) {
-            const int cc = ci < Ci ? ci : 0;
-            wv[ci] = blob[conv_w + co * Ci + cc], xv[ci] = x[cc * kVisPix + i];
-        }
-        float acc = blob[conv_b + co];
+        for (int ci = 0; ci < CM; ++ci) wv[ci] = cw[conv_w + co * Ci + (ci < Ci ? ci : 0)];
+        const float bias = cw[conv_b + co];
+        for (int i = lane; i < kVisPix; i += kWave) {
+            float xv[CM]; /* the taps' loads in flight together, then the chain */
 #pragma unroll
-        for (int ci = 0; ci < CM; ++ci) {
-            const float a2 = mzs_fma(wv[ci], xv[ci], acc);
-            acc = ci < Ci ? a2 : acc;
+            for (int ci = 0; ci < CM; ++ci) xv[ci] = x[(ci < Ci ? ci : 0) * kVisPix + i];
+            float acc = bias;
+#pragma unroll
+            for (int ci = 0; ci < CM; ++ci) {
+                const float a2 = mzs_fma(wv[ci], xv[ci], acc);
+                acc = ci < Ci ? a2 : acc;
+            }
+            t1[co * kVisPix + i] = acc;
         }
-        t1[idx] = acc;
     }
     wave_sync();
-    vis_linear(m.w + fc.in_w, blob + fc.in_b, t1, m.H, kVisHidden, true, t2, lane);
-    float *a = t2, *bb = t1;
-    for (int l = 0; l < m.L; ++l) {
-        vis_linear(m.w + fc.mid_w, blob + fc.mid_b, a, m.H, m.H, true, bb, lane);
-        float* t = a;
-        a = bb;
-        bb = t;
+    /* Linear 147 -> H, (H -> H) x L with one tensor, H -> n_out: one copy of vis_linear for all of them */
+    /* offsets in mzs_vis_mlp_layout's order from fc_base (= its in_w), as plain scalars */
+    const size_t H = (size_t)m.H, in_b = fc_base + H * kVisHidden, mid_w = in_b + H, mid_b = mid_w + (m.L > 0 ? H * H : 0);
+    const size_t out_w = mid_b + (m.L > 0 ? H : 0), out_b = out_w + (size_t)n_out * H;
+    /* the 147-wide layer has a copy of vis_linear of its own (constant fan-in: its partial last batch is
+     * resolved at compile time), the H-wide ones share the second */
+    vis_linear(m.w + fc_base, blob + in_b, t1, m.H, kVisHidden, true, t2, lane);
+    const float* src = t2;
+    float* dst = t1;
+#pragma nounroll
+    for (int l = 1; l < m.L + 2; ++l) {
+        const bool last = l == m.L + 1;
+        vis_linear(m.w + (last ? out_w : mid_w), blob + (last ? out_b : mid_b), src, last ? n_out : m.H, m.H, !last,
+                   last ? logits : dst, lane);
+        float* t = const_cast<float*>(src);
+        src = dst;
+        dst = t;
     }
-    vis_linear(m.w + fc.out_w, blob + fc.out_b, a, fc.n_out, m.H, false, logits, lane);
 }
 
 __device__ __forceinline__ mzs_vision_offsets vis_offsets(const Model& m) {
@@ -253,30 +272,25 @@ __device__ __forceinline__ mzs_vision_offsets vis_offsets(const Model& m) {
 __device__ __forceinline__ void vis_representation(const Model& m, const WaveLds& L, const float* obs_g, float* gdst,
                                                    int lane) {
     const mzs_vision_offsets o = vis_offsets(m);
-    const float* __restrict__ blob = m.blob;
+    const float* blob = L.vc; /* every parameter of the representation is in the cache, at its blob offset */
     float *x = L.ob, *t1 = L.xa, *t2 = L.xb;
     vis_conv3(blob + o.r_conv_in, obs_g, kVisC, MZS_VIS_SIDE, kVisC / 2, 2, x, lane); /* 1 x 49 x 49 */
-    vis_res_block(blob, o.r_res_in, x, MZS_VIS_S1, t1, t2, lane);
-    vis_res_block(blob, o.r_res_in, x, MZS_VIS_S1, t1, t2, lane);
-    vis_conv3(blob + o.r_conv_out, x, kVisC / 2, MZS_VIS_S1, kVisC, 2, t1, lane); /* 3 x 25 x 25 */
-    {
-        float* t = x;
-        x = t1, t1 = t;
+    /* the eight residual blocks through ONE copy of the block's code (the instruction cache again):
+     * res_in x 2 | conv_out -> 3 x 25 x 25 | res_out x 2 | pool -> 13 x 13 | res_out x 3 | pool -> 7 x 7 | res */
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) {
+        if (blk == 2 || blk == 4 || blk == 7) {
+            if (blk == 2)
+                vis_conv3(blob + o.r_conv_out, x, kVisC / 2, MZS_VIS_S1, kVisC, 2, t1, lane);
+            else
+                vis_avgpool(x, kVisC, blk == 4 ? MZS_VIS_S2 : MZS_VIS_S3, t1, lane);
+            float* t = x;
+            x = t1, t1 = t;
+        }
+        const size_t base = blk < 2 ? o.r_res_in.conv_a : (blk == 7 ? o.r_res.conv_a : o.r_res_out.conv_a);
+        const int S = blk < 2 ? MZS_VIS_S1 : (blk < 4 ? MZS_VIS_S2 : (blk < 7 ? MZS_VIS_S3 : MZS_VIS_S4));
+        vis_res_block(blob, base, blk < 2 ? kVisC / 2 : kVisC, x, S, t1, t2, lane);
     }
-    vis_res_block(blob, o.r_res_out, x, MZS_VIS_S2, t1, t2, lane);
-    vis_res_block(blob, o.r_res_out, x, MZS_VIS_S2, t1, t2, lane);
-    vis_avgpool(x, kVisC, MZS_VIS_S2, t1, lane); /* 3 x 13 x 13 */
-    {
-        float* t = x;
-        x = t1, t1 = t;
-    }
-    for (int i = 0; i < 3; ++i) vis_res_block(blob, o.r_res_out, x, MZS_VIS_S3, t1, t2, lane);
-    vis_avgpool(x, kVisC, MZS_VIS_S3, t1, lane); /* 3 x 7 x 7 */
-    {
-        float* t = x;
-        x = t1, t1 = t;
-    }
-    vis_res_block(blob, o.r_res, x, MZS_VIS_S4, t1, t2, lane);
     for (int i = lane; i < kVisHidden; i += kWave) {
         const float v = x[i];
         L.xh[i] = v;
@@ -294,10 +308,11 @@ __device__ __forceinline__ float vis_dynamics(const Model& m, const WaveLds& L, 
     const float pv = (float)(action + 1) / (float)m.A;
     for (int i = lane; i < kVisPix; i += kWave) L.xh[kVisHidden + i] = pv;
     wave_sync();
-    vis_conv3(blob + o.d_conv, L.xh, kVisC + 1, MZS_VIS_S4, kVisC, 1, t1, lane);
-    vis_bn_relu(blob, o.d_bn, t1, kVisC, kVisPix, x, lane);
-    for (int l = 0; l < m.L; ++l) vis_res_block(blob, o.d_res, x, MZS_VIS_S4, t1, t2, lane);
-    vis_head_mlp(m, blob, o.d_conv_rew, o.d_conv_rew_b, kVisC + 1, o.d_fc, L.xh, logits, t1, t2, lane);
+    const float* cw = L.vc;
+    vis_conv3(cw + o.d_conv, L.xh, kVisC + 1, MZS_VIS_S4, kVisC, 1, t1, lane);
+    vis_bn_relu(cw, o.d_bn, t1, kVisC, kVisPix, x, lane);
+    for (int l = 0; l < m.L; ++l) vis_res_block(cw, o.d_res.conv_a, kVisC, x, MZS_VIS_S4, t1, t2, lane);
+    vis_head_mlp(m, blob, cw, o.d_conv_rew, o.d_conv_rew_b, kVisC + 1, o.d_fc.in_w, m.Sd, L.xh, logits, t1, t2, lane);
     const float reward = seg_support_scalar(logits, m.Sd, lane);
     for (int i = lane; i < kVisHidden; i += kWave) {
         const float v = x[i] > 0.0f ? x[i] : 0.0f; /* the Sequential's closing ReLU (:215) */
@@ -315,11 +330,19 @@ __device__ __forceinline__ float vis_prediction(const Model& m, const WaveLds& L
     float *x = L.ob, *t1 = L.xa, *t2 = L.xb, *logits = L.ob + 256;
     for (int i = lane; i < kVisHidden; i += kWave) x[i] = L.xh[i];
     wave_sync();
-    for (int l = 0; l < m.L; ++l) vis_res_block(blob, o.p_res, x, MZS_VIS_S4, t1, t2, lane);
-    vis_head_mlp(m, blob, o.p_conv_val, o.p_conv_val_b, kVisC, o.p_v, x, logits, t1, t2, lane);
-    const float value = seg_support_scalar(logits, m.Sd, lane);
-    wave_sync();
-    vis_head_mlp(m, blob, o.p_conv_pol, o.p_conv_pol_b, kVisC, o.p_p, x, logits, t1, t2, lane);
+    const float* cw = L.vc;
+    const size_t dl = vis_cache_delta(o);
+    for (int l = 0; l < m.L; ++l) vis_res_block(cw, o.p_res.conv_a - dl, kVisC, x, MZS_VIS_S4, t1, t2, lane);
+    float value = 0.0f;
+#pragma nounroll
+    for (int hd = 0; hd < 2; ++hd) { /* value head, then policy head: one copy of the head's code */
+        const size_t cv = (hd ? o.p_conv_pol : o.p_conv_val) - dl, cb = (hd ? o.p_conv_pol_b : o.p_conv_val_b) - dl;
+        vis_head_mlp(m, blob, cw, cv, cb, kVisC, hd ? o.p_p.in_w : o.p_v.in_w, hd ? m.A : m.Sd, x, logits, t1, t2, lane);
+        if (hd == 0) {
+            value = seg_support_scalar(logits, m.Sd, lane);
+            wave_sync();
+        }
+    }
     *policy = seg_softmax(seg_load(logits, m.A, lane));
     wave_sync();
     return value;

@@ -84,6 +84,7 @@ __device__ __forceinline__ WaveLds carve(unsigned char* base, const LdsLayout& l
     L.xa = reinterpret_cast<float*>(base + l.off_xa);
     L.xb = reinterpret_cast<float*>(base + l.off_xb);
     L.ob = reinterpret_cast<float*>(base + l.off_ob);
+    L.vc = reinterpret_cast<float*>(base + l.off_vc);
     return L;
 }
 
@@ -162,6 +163,7 @@ __global__ void __launch_bounds__(256, kVision ? 1 : 4) k_search_fused(const Sea
     if (kInjected) {
         pol = pair_from_global(p.t_root_policy + (size_t)g * A, A, lane);
     } else {
+        if constexpr (kVision) vis_cache_load(m.blob, vis_offsets(m), L.vc, lane);
         /* vision model: the image stays in global memory (3 x 98 x 98 floats per game) */
         const size_t obs_floats = kVision ? (size_t)MZS_VIS_C * m.obs_dim * m.obs_dim : (size_t)m.obs_dim;
         if (!kVision)
@@ -506,6 +508,7 @@ __global__ void __launch_bounds__(256) k_inference(const InferParams p) {
     const int n_in = kMode == kInferInitial ? (vision ? 0 : m.obs_dim) : m.hid;
     for (int k = lane; k < n_in; k += kWave) L.xh[k] = p.in[(size_t)b * n_in + k];
     wave_sync();
+    if constexpr (kVision) vis_cache_load(m.blob, vis_offsets(m), L.vc, lane);
     if (kMode == kInferInitial) {
         model_representation<kVision>(m, L, p.in + (size_t)b * obs_floats, nullptr, lane);
     } else if (kMode == kInferRecurrent) {
@@ -918,6 +921,8 @@ LdsLayout make_lds_layout(const Model& m, int n_nodes, int S) {
     off += act * 4;
     l.off_ob = off;
     off += ob * 4;
+    l.off_vc = off;
+    if (m.kind == MZS_MODEL_VISION) off += kVisCache * 4;
     l.bytes = round_up(off, 16);
     return l;
 }
@@ -1282,6 +1287,11 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
         (d.obs_dim != MZS_VIS_SIDE || d.n_mid_layers < 1 || d.precision != MZS_PRECISION_F32 || d.hidden_dim > 2048))
         return fail(MZS_E_ARG, "vision_model: obs_dim = 98 (the image side, muzero_model.py:314), "
                                "number_of_hidden_layer >= 1, fp32, hidden_layer_dimensions <= 2048");
+    if (d.model_kind == MZS_MODEL_VISION) {
+        const mzs_vision_offsets vo = mzs_vision_layout(&d);
+        if (vo.d_fc.in_w + (vo.p_v.in_w - vo.p_res.conv_a) > (size_t)kVisCache)
+            return fail(MZS_E_ARG, "vision_model: convolution / batchnorm parameters exceed the LDS cache (kVisCache)");
+    }
     if (d.precision != MZS_PRECISION_F32 && d.precision != MZS_PRECISION_BF16)
         return fail(MZS_E_ARG, "precision must be MZS_PRECISION_F32 or MZS_PRECISION_BF16");
     if (d.model_kind == MZS_MODEL_LSTM && (d.n_mid_layers < 1 || d.n_mid_layers > MZS_LSTM_MAX_LAYERS))

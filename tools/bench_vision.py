@@ -21,6 +21,8 @@ def main():
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--weights", default="visA")
+    ap.add_argument("--phases", action="store_true",
+                    help="also time the three inference kernels on the same batch (us per call): where a search's time goes")
     a = ap.parse_args()
     w = np.load(os.path.join(ROOT, "tests", "golden", f"weights_{a.weights}.npz"))
     dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (int(w["kind"]),)
@@ -38,8 +40,26 @@ def main():
     t1.record()
     torch.cuda.synchronize()
     ms = t0.elapsed_time(t1) / a.steps
-    print(json.dumps(dict(model="vision_model", weights=a.weights, dims=dims, games=G, sims=S, ms_per_search=ms,
-                          sims_per_s=G * S / (ms * 1e-3), kernel=eng.search_kernel_name(S))))
+    out = dict(model="vision_model", weights=a.weights, dims=dims, games=G, sims=S, ms_per_search=ms,
+               sims_per_s=G * S / (ms * 1e-3), kernel=eng.search_kernel_name(S))
+    if a.phases:
+        def timed(fn, n=20):
+            fn()
+            torch.cuda.synchronize()
+            t0.record()
+            for _ in range(n):
+                fn()
+            t1.record()
+            torch.cuda.synchronize()
+            return 1e3 * t0.elapsed_time(t1) / n
+        hid, _, _ = eng.initial_inference(obs)
+        act = torch.zeros(G, dtype=torch.int32).cuda()
+        out["us_initial"] = timed(lambda: eng.initial_inference(obs))
+        out["us_representation"] = timed(lambda: eng.initial_inference(obs, want_prediction=False))
+        out["us_recurrent"] = timed(lambda: eng.recurrent_inference(hid, act))
+        out["us_dynamics"] = timed(lambda: eng.recurrent_inference(hid, act, want_prediction=False))
+        out["us_prediction"] = timed(lambda: eng.prediction_inference(hid))
+    print(json.dumps(out))
 
 
 if __name__ == "__main__":
