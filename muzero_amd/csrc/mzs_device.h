@@ -385,10 +385,10 @@ __device__ __forceinline__ void model_representation(const Model& m, const WaveL
 
 /* Dynamics_function.forward on L.xh + action: reward returned (uniform), next hidden
  * state to L.xh and gdst */
-template <bool kVision>
+template <bool kVision, int kVisBatch = 64>
 __device__ __forceinline__ float model_dynamics(const Model& m, const WaveLds& L, int action,
                                                 float* gdst, int lane) {
-    if constexpr (kVision) return vis_dynamics(m, L, action, gdst, lane);
+    if constexpr (kVision) return vis_dynamics<kVisBatch>(m, L, action, gdst, lane);
     if (m.kind == MZS_MODEL_LSTM) {
         const float* r = lstm_head(m, m.l_rew, L, L.xh, m.Sd + action, lane);
         const float reward = seg_support_scalar(r, m.Sd, lane);
@@ -406,10 +406,10 @@ __device__ __forceinline__ float model_dynamics(const Model& m, const WaveLds& L
 }
 
 /* Prediction_function.forward on L.xh: softmax policy as lane pairs, value (uniform) */
-template <bool kVision>
+template <bool kVision, int kVisBatch = 64>
 __device__ __forceinline__ float model_prediction(const Model& m, const WaveLds& L, Pair* policy,
                                                   int lane) {
-    if constexpr (kVision) return vis_prediction(m, L, policy, lane);
+    if constexpr (kVision) return vis_prediction<kVisBatch>(m, L, policy, lane);
     if (m.kind == MZS_MODEL_LSTM) {
         const float* pl = lstm_head(m, m.l_pol, L, L.xh, -1, lane);
         *policy = seg_softmax(seg_load(pl, m.A, lane));

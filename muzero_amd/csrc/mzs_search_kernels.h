@@ -27,6 +27,7 @@ namespace mzs {
 /* byte offsets inside one wave's LDS slice */
 struct LdsLayout {
     int off_cb, off_path, off_xh, off_xa, off_xb, off_ob, off_vc, bytes;
+    int shared_bytes; /* per workgroup, behind the waves' slices (vision search: the parameter cache) */
 };
 
 struct TreeArrays {

@@ -46,6 +46,16 @@ __device__ __forceinline__ void vis_cache_load(const float* __restrict__ blob, c
     wave_sync();
 }
 
+/* the same into ONE copy per workgroup (the search kernel: the per-wave LDS slice decides how many waves a
+ * SIMD holds); every thread of the block calls it, before any wave leaves */
+__device__ __forceinline__ void vis_cache_load_block(const float* __restrict__ blob, const mzs_vision_offsets& o,
+                                                     float* vc) {
+    const int n1 = (int)o.d_fc.in_w, n2 = (int)(o.p_v.in_w - o.p_res.conv_a);
+    for (int i = threadIdx.x; i < n1; i += blockDim.x) vc[i] = blob[i];
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) vc[n1 + i] = blob[o.p_res.conv_a + i];
+    __syncthreads();
+}
+
 /* out [Co][So][So] = conv3x3(in [Ci][Si][Si]), stride s, padding 1, no bias; in: LDS or global; w: the
  * cached weights.  Output channels in turn (their Ci x 9 weights in registers, the same for every lane),
  * one output pixel per lane and pass; the pass's Ci x 9 inputs are all fetched (a padding tap reads a
@@ -169,13 +179,14 @@ __device__ __forceinline__ void vis_avgpool(const float* in, int C, int Si, floa
 }
 
 /* y = [relu](b + W x), contract "dot" (even / odd chains); Wt = W^T [nin][nout] (the transposed copy
- * mzs_set_weights makes: lanes read neighbouring addresses).  Sixty-four rows are requested ahead of the
- * chains that consume them (a trip to L2 per batch: three for the 147-wide layer, one for the others,
- * where batches of sixteen made ten and four); the last, partial batch reads clamped rows and skips them
- * by a select. */
+ * mzs_set_weights makes: lanes read neighbouring addresses).  NB rows are requested ahead of the chains
+ * that consume them (a trip to L2 per batch; NB = 64: three for the 147-wide layer, one for the others,
+ * where batches of sixteen made ten and four; NB = 32 where four waves share a SIMD and 128 registers);
+ * the last, partial batch reads clamped rows and skips them by a select. */
+template <int NB>
 __device__ __forceinline__ void vis_linear(const float* __restrict__ Wt, const float* __restrict__ b, const float* x,
                                            int nout, int nin, bool relu, float* y, int lane) {
-    constexpr int NB = 64, NT = 32;
+    constexpr int NT = 32;
     for (int j = lane; j < nout; j += kWave) {
         const float* __restrict__ w = Wt + j;
         float e = b[j], o = 0.0f;
@@ -218,6 +229,7 @@ __device__ __forceinline__ void vis_linear(const float* __restrict__ Wt, const f
 
 /* 1x1 convolution (+bias) of x [Ci][49] -> flatten -> Linear, relu, (Linear, relu) x L, Linear: logits.
  * cw: the cached parameters (conv_w, conv_b are blob offsets into them) */
+template <int NB>
 __device__ __forceinline__ void vis_head_mlp(const Model& m, const float* __restrict__ blob, const float* cw,
                                              size_t conv_w, size_t conv_b, int Ci, size_t fc_base, int n_out,
                                              const float* x, float* logits, float* t1, float* t2, int lane) {
@@ -247,13 +259,13 @@ __device__ __forceinline__ void vis_head_mlp(const Model& m, const float* __rest
     const size_t out_w = mid_b + (m.L > 0 ? H : 0), out_b = out_w + (size_t)n_out * H;
     /* the 147-wide layer has a copy of vis_linear of its own (constant fan-in: its partial last batch is
      * resolved at compile time), the H-wide ones share the second */
-    vis_linear(m.w + fc_base, blob + in_b, t1, m.H, kVisHidden, true, t2, lane);
+    vis_linear<NB>(m.w + fc_base, blob + in_b, t1, m.H, kVisHidden, true, t2, lane);
     const float* src = t2;
     float* dst = t1;
 #pragma nounroll
     for (int l = 1; l < m.L + 2; ++l) {
         const bool last = l == m.L + 1;
-        vis_linear(m.w + (last ? out_w : mid_w), blob + (last ? out_b : mid_b), src, last ? n_out : m.H, m.H, !last,
+        vis_linear<NB>(m.w + (last ? out_w : mid_w), blob + (last ? out_b : mid_b), src, last ? n_out : m.H, m.H, !last,
                    last ? logits : dst, lane);
         float* t = const_cast<float*>(src);
         src = dst;
@@ -300,6 +312,7 @@ __device__ __forceinline__ void vis_representation(const Model& m, const WaveLds
 }
 
 /* hidden state in L.xh + action -> reward (returned, uniform); next hidden state to L.xh and gdst */
+template <int NB = 64>
 __device__ __forceinline__ float vis_dynamics(const Model& m, const WaveLds& L, int action, float* gdst, int lane) {
     const mzs_vision_offsets o = vis_offsets(m);
     const float* __restrict__ blob = m.blob;
@@ -312,7 +325,7 @@ __device__ __forceinline__ float vis_dynamics(const Model& m, const WaveLds& L, 
     vis_conv3(cw + o.d_conv, L.xh, kVisC + 1, MZS_VIS_S4, kVisC, 1, t1, lane);
     vis_bn_relu(cw, o.d_bn, t1, kVisC, kVisPix, x, lane);
     for (int l = 0; l < m.L; ++l) vis_res_block(cw, o.d_res.conv_a, kVisC, x, MZS_VIS_S4, t1, t2, lane);
-    vis_head_mlp(m, blob, cw, o.d_conv_rew, o.d_conv_rew_b, kVisC + 1, o.d_fc.in_w, m.Sd, L.xh, logits, t1, t2, lane);
+    vis_head_mlp<NB>(m, blob, cw, o.d_conv_rew, o.d_conv_rew_b, kVisC + 1, o.d_fc.in_w, m.Sd, L.xh, logits, t1, t2, lane);
     const float reward = seg_support_scalar(logits, m.Sd, lane);
     for (int i = lane; i < kVisHidden; i += kWave) {
         const float v = x[i] > 0.0f ? x[i] : 0.0f; /* the Sequential's closing ReLU (:215) */
@@ -324,6 +337,7 @@ __device__ __forceinline__ float vis_dynamics(const Model& m, const WaveLds& L, 
 }
 
 /* hidden state in L.xh (kept) -> softmax policy as lane pairs, value (uniform) */
+template <int NB = 64>
 __device__ __forceinline__ float vis_prediction(const Model& m, const WaveLds& L, Pair* policy, int lane) {
     const mzs_vision_offsets o = vis_offsets(m);
     const float* __restrict__ blob = m.blob;
@@ -337,7 +351,7 @@ __device__ __forceinline__ float vis_prediction(const Model& m, const WaveLds& L
 #pragma nounroll
     for (int hd = 0; hd < 2; ++hd) { /* value head, then policy head: one copy of the head's code */
         const size_t cv = (hd ? o.p_conv_pol : o.p_conv_val) - dl, cb = (hd ? o.p_conv_pol_b : o.p_conv_val_b) - dl;
-        vis_head_mlp(m, blob, cw, cv, cb, kVisC, hd ? o.p_p.in_w : o.p_v.in_w, hd ? m.A : m.Sd, x, logits, t1, t2, lane);
+        vis_head_mlp<NB>(m, blob, cw, cv, cb, kVisC, hd ? o.p_p.in_w : o.p_v.in_w, hd ? m.A : m.Sd, x, logits, t1, t2, lane);
         if (hd == 0) {
             value = seg_support_scalar(logits, m.Sd, lane);
             wave_sync();

@@ -110,16 +110,23 @@ __device__ __forceinline__ void pair_to_global(float* row, const Pair p, int lan
  * one game per wavefront, all simulations in one launch, tree resident in LDS and
  * written to the HBM structure-of-arrays once at the end.
  * ---------------------------------------------------------------------------- */
-template <bool kInjected, bool kVision = false>
-__global__ void __launch_bounds__(256, kVision ? 1 : 4) k_search_fused(const SearchParams p) {
+/* kVisWaves (vision model): waves per SIMD the kernel is compiled for — 2: up to 256 registers, the Linear
+ * layers request 64 rows per batch; 4: 128 registers, 32 rows per batch (search_launch picks by game count) */
+template <bool kInjected, bool kVision = false, int kVisWaves = 4>
+__global__ void __launch_bounds__(256, kVision ? kVisWaves : 4) k_search_fused(const SearchParams p) {
+    constexpr int kVisBatch = kVisWaves >= 4 ? 32 : 64;
     extern __shared__ __align__(16) unsigned char smem[];
     const int lane = lane_id();
     const int wave = threadIdx.x >> 6;
     const int g = blockIdx.x * (blockDim.x >> 6) + wave;
     if (redo_skip_block(p, blockDim.x >> 6)) return;
-    if (g >= p.n_games || (p.redo && p.t.status[g] == 0)) return; /* no block-level barrier anywhere below */
-    const WaveLds L = carve(smem + (size_t)wave * p.lds.bytes, p.lds);
+    WaveLds L = carve(smem + (size_t)wave * p.lds.bytes, p.lds);
     const Model& m = p.m;
+    if constexpr (kVision && !kInjected) { /* the block's copy of the convolution / batchnorm parameters */
+        L.vc = reinterpret_cast<float*>(smem + (size_t)(blockDim.x >> 6) * p.lds.bytes);
+        vis_cache_load_block(m.blob, vis_offsets(m), L.vc);
+    }
+    if (g >= p.n_games || (p.redo && p.t.status[g] == 0)) return; /* no block-level barrier anywhere below */
     const int A = m.A, S = p.S;
 
     SearchConst c;
@@ -162,15 +169,17 @@ __global__ void __launch_bounds__(256, kVision ? 1 : 4) k_search_fused(const Sea
     Pair pol;
     if (kInjected) {
         pol = pair_from_global(p.t_root_policy + (size_t)g * A, A, lane);
+    } else if constexpr (kVision) {
+        /* vision model: the root was evaluated by k_inference<initial, vision> (search_launch): its hidden
+         * state is row 0 of the game's hidden rows, its policy in t_root_policy.  The representation needs
+         * three 49 x 49 maps of LDS per wave — one wave per SIMD; the simulations need ~6 KB per wave
+         * and run here at up to four waves per SIMD */
+        pol = pair_from_global(p.t_root_policy + (size_t)g * A, A, lane);
     } else {
-        if constexpr (kVision) vis_cache_load(m.blob, vis_offsets(m), L.vc, lane);
-        /* vision model: the image stays in global memory (3 x 98 x 98 floats per game) */
-        const size_t obs_floats = kVision ? (size_t)MZS_VIS_C * m.obs_dim * m.obs_dim : (size_t)m.obs_dim;
-        if (!kVision)
-            for (int k = lane; k < m.obs_dim; k += kWave) L.xh[k] = p.obs[(size_t)g * m.obs_dim + k];
+        for (int k = lane; k < m.obs_dim; k += kWave) L.xh[k] = p.obs[(size_t)g * m.obs_dim + k];
         wave_sync();
-        model_representation<kVision>(m, L, p.obs + (size_t)g * obs_floats, hid_g, lane);
-        (void)model_prediction<kVision>(m, L, &pol, lane);
+        model_representation<false>(m, L, p.obs + (size_t)g * m.obs_dim, hid_g, lane);
+        (void)model_prediction<false>(m, L, &pol, lane);
     }
     wave_expand(c, L, 0, 0, 0.0f, pol, lane);
     /* add_exploration_noise_at_the_root (mcts.py:134-145): f32 product widened, f64 sum */
@@ -197,8 +206,8 @@ __global__ void __launch_bounds__(256, kVision ? 1 : 4) k_search_fused(const Sea
             const float* hp = hid_g + (size_t)e_parent * p.t.hid_stride;
             for (int k = lane; k < m.hid; k += kWave) L.xh[k] = hp[k];
             wave_sync();
-            reward = model_dynamics<kVision>(m, L, action, hid_g + (size_t)e_new * p.t.hid_stride, lane);
-            value = model_prediction<kVision>(m, L, &pol, lane);
+            reward = model_dynamics<kVision, kVisBatch>(m, L, action, hid_g + (size_t)e_new * p.t.hid_stride, lane);
+            value = model_prediction<kVision, kVisBatch>(m, L, &pol, lane);
         }
         wave_expand(c, L, leaf, e_new, reward, pol, lane);
         if (lane == 0) p.t.sim_leaf[(size_t)g * p.t.max_sims + sim] = leaf;
@@ -490,6 +499,7 @@ struct InferParams {
     float* hidden_out;     /* [B][hid]                           */
     float* policy;         /* [B][A]                             */
     float* value;          /* [B]                                */
+    long long hidden_stride; /* floats between the rows of hidden_out (0: hid) */
 };
 
 enum { kInferInitial = 0, kInferRecurrent = 1, kInferPrediction = 2 };
@@ -515,8 +525,10 @@ __global__ void __launch_bounds__(256) k_inference(const InferParams p) {
         const float reward = model_dynamics<kVision>(m, L, p.action[b], nullptr, lane);
         if (lane == 0) p.reward[b] = reward;
     }
-    if (kMode != kInferPrediction)
-        for (int k = lane; k < m.hid; k += kWave) p.hidden_out[(size_t)b * m.hid + k] = L.xh[k];
+    if (kMode != kInferPrediction) {
+        const size_t hs = p.hidden_stride ? (size_t)p.hidden_stride : (size_t)m.hid;
+        for (int k = lane; k < m.hid; k += kWave) p.hidden_out[(size_t)b * hs + k] = L.xh[k];
+    }
     if (p.policy || p.value) {
         Pair pol;
         const float value = model_prediction<kVision>(m, L, &pol, lane);
@@ -737,6 +749,7 @@ struct mzs_handle {
     int* store_index_dev = nullptr; /* blob element -> offset in the device weight store        */
     double* pbc_dev = nullptr;
     int* overflow_dev = nullptr;   /* set by a search that ran out of tie-break draws (mzs_search_streams) */
+    float* root_policy_dev = nullptr; /* vision model: [max_games][A] root policies (k_inference -> k_search_fused) */
     float* stream_dev = nullptr;   /* chunk images (k_build_stream) of the models that have a quadw / quadl kernel */
     StreamPlan stream_plan;
     /* training (mzs_train_*): allocated by mzs_train_create */
@@ -892,7 +905,7 @@ void describe_model(const mzs_dims& d, Model* m, StoreBuilder* sb) {
     m->p_heads = sb->add(H, H, round_up(m->seg_value + Sd, 64));
 }
 
-LdsLayout make_lds_layout(const Model& m, int n_nodes, int S) {
+LdsLayout make_lds_layout(const Model& m, int n_nodes, int S, bool vis_sims_only = false) {
     LdsLayout l;
     int off = round_up(n_nodes * (int)sizeof(Node), 16);
     l.off_cb = off;
@@ -912,8 +925,13 @@ LdsLayout make_lds_layout(const Model& m, int n_nodes, int S) {
     }
     if (m.kind == MZS_MODEL_VISION) { /* mzs_vision.h: three maps of up to 49 x 49 floats, logits behind the third's head */
         off = l.off_xh + kVisXh * 4;
-        act = kVisBuf > act ? kVisBuf : act;
-        ob = kVisBuf;
+        if (vis_sims_only) { /* dynamics / prediction on 7 x 7 maps: 4 x 49 floats, H activations, logits at ob + 256 */
+            act = act > 256 ? act : 256;
+            ob = 256 + 128;
+        } else {
+            act = kVisBuf > act ? kVisBuf : act;
+            ob = kVisBuf;
+        }
     }
     l.off_xa = off;
     off += act * 4;
@@ -922,7 +940,13 @@ LdsLayout make_lds_layout(const Model& m, int n_nodes, int S) {
     l.off_ob = off;
     off += ob * 4;
     l.off_vc = off;
-    if (m.kind == MZS_MODEL_VISION) off += kVisCache * 4;
+    l.shared_bytes = 0;
+    if (m.kind == MZS_MODEL_VISION) {
+        if (vis_sims_only)
+            l.shared_bytes = kVisCache * 4; /* one copy per workgroup (k_search_fused) */
+        else
+            off += kVisCache * 4;
+    }
     l.bytes = round_up(off, 16);
     return l;
 }
@@ -932,7 +956,7 @@ constexpr int kMaxLdsPerBlock = 160 * 1024;
 /* waves per block so that the block's LDS fits; 0 if even one wave does not */
 int waves_per_block(const LdsLayout& l) {
     int w = 4;
-    while (w > 0 && w * l.bytes > kMaxLdsPerBlock) --w;
+    while (w > 0 && w * l.bytes + l.shared_bytes > kMaxLdsPerBlock) --w;
     return w;
 }
 
@@ -941,7 +965,7 @@ int launch(K kernel, const P& params, int units, const LdsLayout& lds, hipStream
     const int wpb = waves_per_block(lds);
     if (wpb == 0) return fail(MZS_E_ARG, "problem too large for one wave's LDS slice");
     const int blocks = (units + wpb - 1) / wpb;
-    const size_t shmem = (size_t)wpb * lds.bytes;
+    const size_t shmem = (size_t)wpb * lds.bytes + lds.shared_bytes;
     if (shmem > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem));
@@ -1325,7 +1349,7 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     h->w_floats = sb.data.size();
     if (d.model_kind == MZS_MODEL_VISION) h->w_floats = mzs_blob_total(&d); /* the blob with its Linear weights transposed */
     h->n_nodes_max = mzs_nodes_per_game(d.n_actions, cfg->max_simulations);
-    h->lds = make_lds_layout(h->model, h->n_nodes_max, cfg->max_simulations);
+    h->lds = make_lds_layout(h->model, h->n_nodes_max, cfg->max_simulations, d.model_kind == MZS_MODEL_VISION);
     if (waves_per_block(h->lds) == 0) {
         delete h;
         return fail(MZS_E_ARG, "tree + activations of one game exceed 160 KiB of LDS");
@@ -1368,6 +1392,11 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
         }
     }
     if ((rc = dev_alloc(h, &h->overflow_dev, 64))) {
+        mzs_destroy(h);
+        return rc;
+    }
+    if (d.model_kind == MZS_MODEL_VISION &&
+        (rc = dev_alloc(h, &h->root_policy_dev, (size_t)cfg->max_games * d.n_actions))) {
         mzs_destroy(h);
         return rc;
     }
@@ -1492,9 +1521,29 @@ static int search_launch(mzs_handle* h, int32_t n_games, int32_t S, int32_t trai
     p.overflow = h->overflow_dev;
     p.redo = redo;
     const SearchPlan plan = plan_search(h, S, n_games);
-    if (plan.kind == kPlanGeneric)
-        return h->cfg.dims.model_kind == MZS_MODEL_VISION ? launch(k_search_fused<false, true>, p, n_games, p.lds, st)
-                                                          : launch(k_search_fused<false>, p, n_games, p.lds, st);
+    if (plan.kind == kPlanGeneric && h->cfg.dims.model_kind == MZS_MODEL_VISION) {
+        /* two launches: the roots (representation + prediction, one wave per SIMD for its LDS), then the
+         * simulations on a small LDS slice.  A redo pass finds the roots where the first pass left them. */
+        if (!redo) {
+            InferParams ip;
+            std::memset(&ip, 0, sizeof ip);
+            ip.m = h->model;
+            ip.lds = make_lds_layout(h->model, 1, 0);
+            ip.batch = n_games;
+            ip.in = obs_dev;
+            ip.hidden_out = h->tree.hidden;
+            ip.hidden_stride = (long long)(h->tree.max_sims + 1) * h->tree.hid_stride;
+            ip.policy = h->root_policy_dev;
+            const int rc = launch(k_inference<kInferInitial, true>, ip, n_games, ip.lds, st);
+            if (rc) return rc;
+        }
+        p.t_root_policy = h->root_policy_dev;
+        p.lds = make_lds_layout(h->model, p.n_nodes, S, true);
+        /* up to two waves per SIMD's worth of games: the build with 256 registers; more: four per SIMD */
+        return n_games <= 8 * h->n_cus ? launch(k_search_fused<false, true, 2>, p, n_games, p.lds, st)
+                                       : launch(k_search_fused<false, true, 4>, p, n_games, p.lds, st);
+    }
+    if (plan.kind == kPlanGeneric) return launch(k_search_fused<false>, p, n_games, p.lds, st);
     if (plan.kind == kPlanStream) {
         if (build_stream) {
             hipLaunchKernelGGL(k_build_stream, dim3(h->stream_plan.n), dim3(256), 0, st, h->w_search_dev,

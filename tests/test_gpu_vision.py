@@ -81,6 +81,35 @@ def test_vision_search_equals_oracle(name, G, S):
     eng.close()
 
 
+def test_vision_search_many_games_equals_oracle():
+    """More games than two wavefronts per SIMD hold (8 x CUs): search_launch switches to the build of the
+    simulation kernel compiled for four waves per SIMD (128 registers, 32-row Linear batches).  Its
+    results on 8 x CUs + 256 games — copies of twelve distinct games — equal the oracle's for those
+    twelve, bit for bit, in every copy."""
+    import torch
+    from muzero_amd import rng  # noqa: F401
+    from oracle import mz_oracle as mzo
+    name, K, S = "visA", 12, 12
+    d, blob = fixture_weights(name)
+    G = 8 * torch.cuda.get_device_properties(0).multi_processor_count + 256
+    obs_k = np.random.RandomState(11).uniform(0.0, 1.0, size=(K, 3, 98, 98)).astype(np.float32)
+    seeds_k = np.arange(K, dtype=np.int64) + 77
+    idx = np.arange(G) % K
+    eng = engine_for(d, G, S, discount=0.997)
+    eng.set_weights(blob)
+    eng.search_streams(torch.as_tensor(obs_k).cuda()[torch.as_tensor(idx).cuda()], seeds_k[idx], S, True)
+    out, tree = eng.results_host(), eng.tree_host()
+    dirichlet, noise = eng.fill_streams(seeds_k, S, True)
+    ref = mzo.search(d, blob, S, 0.997, 0.25, eng.pbc, obs=obs_k, dirichlet=dirichlet.cpu().numpy(),
+                     noise=noise.cpu().numpy(), train=True, want=("visits", "root_value", "consumed", "hidden"))
+    assert np.array_equal(out["visits"], ref["visits"][idx])
+    assert np.array_equal(bits(out["root_value"]), bits(ref["root_value"][idx]))
+    assert np.array_equal(out["consumed"], ref["consumed"][idx])
+    assert np.array_equal(bits(tree["hidden"]), bits(ref["hidden"][idx]))
+    assert np.all(tree["status"] == 0)
+    eng.close()
+
+
 def test_vision_muzero_drop_in():
     """Muzero(model_structure='vision_model'): the reference's wrapper surface (muzero_model.py:828-905)
     — (1, 3, 98, 98) observations, (1, 3, 7, 7) hidden states — against the reference's own outputs, a
