@@ -5,9 +5,9 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/prof_vision
 mkdir -p $OUT
 export TMPDIR=/tmp
-timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/bench_vision.py --steps 5 > $OUT/bench_trace.json
-timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -- python3 tools/bench_vision.py --steps 3 > $OUT/bench_sq.json
-timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_act -- python3 tools/bench_vision.py --steps 3 > $OUT/bench_act.json 2> $OUT/pmc_act.err || echo "act pass failed"
+timeout -s KILL 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- python3 tools/bench_vision.py --games 4096 --steps 5 > $OUT/bench_trace.json
+timeout -s KILL 120 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAIT_ANY --output-format csv -d $OUT/pmc_sq -- python3 tools/bench_vision.py --games 4096 --steps 3 > $OUT/bench_sq.json
+timeout -s KILL 120 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM_RD SQ_WAIT_INST_LDS --output-format csv -d $OUT/pmc_act -- python3 tools/bench_vision.py --games 4096 --steps 3 > $OUT/bench_act.json 2> $OUT/pmc_act.err || echo "act pass failed"
 python3 - <<'PY'
 import csv, glob, collections
 print("## kernel-trace --stats")
@@ -21,7 +21,7 @@ for p in ("pmc_sq", "pmc_act"):
             agg[r["Kernel_Name"][:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
     print(f"## --pmc {p} (mean per launch)")
     for k, c in agg.items():
-        if "search" in k:
+        if "search" in k or "inference" in k:
             for a, v in sorted(c.items()):
                 print("|", k, "|", a, "|", round(sum(v) / len(v), 1), "|", len(v), "|")
 PY
