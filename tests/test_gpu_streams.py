@@ -36,6 +36,30 @@ def test_streams_equal_randomstate(A, S, train):
     eng.close()
 
 
+@pytest.mark.parametrize("alpha", [0.03, 0.25, 0.5, 0.9, 1.0])
+@pytest.mark.parametrize("A,S", [(2, 30), (5, 12), (18, 6), (64, 3)])
+def test_streams_other_alphas_and_action_counts(alpha, A, S):
+    """root_dirichlet_alpha from 0.03 to 1 (1: the exponential branch of the legacy gamma sampler) and up to 64
+    actions — with 64, fewer than A of the 64 rejection attempts a wave evaluates at once are accepted, so the
+    scalar continuation of the sampler runs too — on 600 random seeds: uniforms bit for bit, Dirichlet rows
+    within a few ulp (same accept / reject path, else the uniforms behind them would be shifted)."""
+    from muzero_amd import rng
+    from muzero_amd.engine import SearchEngine
+    G = 600
+    eng = SearchEngine((4, A, 31, 64, 0), max_games=G, max_simulations=S, root_dirichlet_alpha=alpha)
+    seeds = np.random.RandomState(int(alpha * 100) + A).randint(0, 2 ** 32 - 1, size=G).astype(np.int64)
+    dirichlet, noise = eng.fill_streams(seeds, S, True)
+    ref_d, ref_n = rng.noise_streams(seeds, A, S, alpha, True)
+    n_u = rng.max_draws(A, S)
+    assert np.array_equal(noise.cpu().numpy()[:, :n_u].view(np.uint64), ref_n[:, :n_u].view(np.uint64))
+    d = dirichlet.cpu().numpy()
+    big = ref_d > 1e-300                      # alpha 0.03: components underflow towards 0, ulps lose meaning there
+    ulps = np.abs(d - ref_d)[big] / np.spacing(np.abs(ref_d[big]))
+    assert ulps.max() <= 16, ulps.max()
+    assert np.allclose(d[~big], ref_d[~big], atol=1e-300)
+    eng.close()
+
+
 def test_run_batch_with_device_streams_matches_oracle():
     """run_batch(seeds=...) end to end: streams made on the GPU, search == oracle search fed the
     very same streams, and == the host-stream search wherever the Dirichlet bits agree."""
