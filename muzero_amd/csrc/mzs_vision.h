@@ -25,7 +25,8 @@
 namespace mzs {
 
 constexpr int kVisC = MZS_VIS_C, kVisHidden = MZS_VIS_HIDDEN, kVisPix = MZS_VIS_S4 * MZS_VIS_S4;
-constexpr int kVisBuf = 2432;  /* floats of one scratch map: >= 49 * 49, >= 3 * 25 * 25 */
+constexpr int kVisBuf = 2432;  /* floats of one scratch map: >= 49 * 49, >= 3 * 25 * 25, >= 3 * 27 * 27 (with border) */
+constexpr int kVisPadBuf = 2608; /* the map with its border at 49 x 49: 51 * 51 */
 constexpr int kVisXh = 208;    /* hidden state (147) + action plane (49), rounded */
 
 /* The small parameters (every convolution and batchnorm: blob ranges [0, d_fc.in_w) and [p_res.conv_a,
@@ -62,48 +63,58 @@ __device__ __forceinline__ void vis_cache_load_block(const float* __restrict__ b
  * clamped address and is marked) BEFORE the fma chain that consumes them in (ci, ky, kx) order, padding
  * taps skipped by a select — the wave is alone on its SIMD, so a chain that waits for a load per tap (as
  * the plain loop did) is bound by 27-36 load latencies per output. */
-template <int CI>
+template <int CI, int NP = 1>
 __device__ __forceinline__ void vis_conv3_t(const float* w, const float* in, int Si, int Co, int s, float* out,
                                             int lane) {
+    /* NP: passes whose taps are requested together (the first convolution reads the image from global
+     * memory: a pass at a time waits out a trip to HBM per 64 outputs, 38 of them) */
     const int So = (Si - 1) / s + 1, n = So * So;
     const float inv_so = 1.0f / (float)So; /* r / So below: r < 2401, So <= 49, exact with the half offset */
     for (int co = 0; co < Co; ++co) {
         float wv[CI * 9];
 #pragma unroll
         for (int j = 0; j < CI * 9; ++j) wv[j] = w[co * CI * 9 + j];
-        for (int r0 = 0; r0 < n; r0 += kWave) {
-            const bool live = r0 + lane < n;
-            const int r = live ? r0 + lane : 0;
-            const int oy = (int)(((float)r + 0.5f) * inv_so), ox = r - oy * So;
-            float xv[CI * 9];
-            bool ok[9];
-            int off[9];
+        for (int r0 = 0; r0 < n; r0 += NP * kWave) {
+            float xv[NP][CI * 9];
+            unsigned okm[NP]; /* bit t: tap t lies inside the map; bit 9: the output exists */
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
+            for (int p = 0; p < NP; ++p) {
+                const bool live = r0 + p * kWave + lane < n;
+                const int r = live ? r0 + p * kWave + lane : 0;
+                const int oy = (int)(((float)r + 0.5f) * inv_so), ox = r - oy * So;
+                int off[9];
+                unsigned m = live ? 512u : 0u;
 #pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int iy = oy * s + ky - 1, ix = ox * s + kx - 1;
-                    const bool v = iy >= 0 && iy < Si && ix >= 0 && ix < Si;
-                    ok[ky * 3 + kx] = v;
-                    off[ky * 3 + kx] = v ? iy * Si + ix : 0;
+                for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int iy = oy * s + ky - 1, ix = ox * s + kx - 1;
+                        const bool v = iy >= 0 && iy < Si && ix >= 0 && ix < Si;
+                        m |= v ? 1u << (ky * 3 + kx) : 0u;
+                        off[ky * 3 + kx] = v ? iy * Si + ix : 0;
+                    }
+                }
+                okm[p] = m;
+#pragma unroll
+                for (int ci = 0; ci < CI; ++ci) {
+                    const float* ip = in + (size_t)ci * Si * Si;
+#pragma unroll
+                    for (int t = 0; t < 9; ++t) xv[p][ci * 9 + t] = ip[off[t]];
                 }
             }
 #pragma unroll
-            for (int ci = 0; ci < CI; ++ci) {
-                const float* ip = in + (size_t)ci * Si * Si;
+            for (int p = 0; p < NP; ++p) {
+                float acc = 0.0f;
 #pragma unroll
-                for (int t = 0; t < 9; ++t) xv[ci * 9 + t] = ip[off[t]];
-            }
-            float acc = 0.0f;
+                for (int ci = 0; ci < CI; ++ci) {
 #pragma unroll
-            for (int ci = 0; ci < CI; ++ci) {
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const float a2 = mzs_fma(wv[ci * 9 + t], xv[ci * 9 + t], acc);
-                    acc = ok[t] ? a2 : acc;
+                    for (int t = 0; t < 9; ++t) {
+                        const float a2 = mzs_fma(wv[ci * 9 + t], xv[p][ci * 9 + t], acc);
+                        acc = (okm[p] >> t) & 1u ? a2 : acc;
+                    }
                 }
+                if (okm[p] & 512u) out[co * n + r0 + p * kWave + lane] = acc;
             }
-            if (live) out[co * n + r] = acc;
         }
     }
     wave_sync();
@@ -134,22 +145,144 @@ __device__ __forceinline__ void vis_bn_relu(const float* cw, const mzs_vis_bn& b
     wave_sync();
 }
 
+/* A residual block's stage, conv3x3(relu(batchnorm(in))) with C -> C channels, in two passes over a map with
+ * a border: vis_bn_relu_pad writes relu(batchnorm(in)) into pad [C][S + 2][S + 2] with a border of +0 (the
+ * convolution's zero padding, materialised), vis_conv3_pad then reads a pixel's C x 9 taps at constant offsets
+ * from one address — no bounds tests, no selects — and runs the C output channels' chains over them in
+ * (ci, ky, kx) order.  A padding tap contributes fma(w, +0, acc) == acc bit for bit (acc starts at +0 and a
+ * sum is -0 only if both addends are), so adding it and skipping it, as the contract words it, are the same
+ * for finite weights.  Measured on the 49 x 49 stage: 800 cycles per 64 outputs with the bounds tests and
+ * selects of the plain form (~130 instructions for 9 taps), a third of that in this form. */
+template <int C>
+__device__ __forceinline__ void vis_bn_relu_pad(const float* cw, const mzs_vis_bn& bn, const float* in, int S, float* pad,
+                                                int lane) {
+    const int P = S + 2, n = S * S, np = P * P;
+    const float inv_p = 1.0f / (float)P; /* q / P below: q < 2601, P <= 51, exact with the half offset */
+    float iv[C], mu[C], be[C];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float g = cw[bn.w + c], var = cw[bn.var + c];
+        mu[c] = cw[bn.mean + c], be[c] = cw[bn.b + c];
+        iv[c] = g / __builtin_sqrtf(var + 1e-5f);
+    }
+    for (int q0 = 0; q0 < np; q0 += kWave) {
+        const int q = q0 + lane;
+        const bool live = q < np;
+        const int py = (int)(((float)(live ? q : 0) + 0.5f) * inv_p), px = (live ? q : 0) - py * P;
+        const bool inner = live && py >= 1 && py <= S && px >= 1 && px <= S;
+        const int src = inner ? (py - 1) * S + px - 1 : 0;
+        float xv[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) xv[c] = in[c * n + src];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float y = mzs_fma(xv[c] - mu[c], iv[c], be[c]);
+            if (live) pad[c * np + q] = inner && y > 0.0f ? y : 0.0f;
+        }
+    }
+    wave_sync();
+}
+
+template <int C, bool kHoist>
+__device__ __forceinline__ void vis_conv3_pad(const float* cw, size_t w_off, const float* pad, int S, float* out,
+                                              int lane) {
+    const int P = S + 2, n = S * S, np = P * P;
+    /* kHoist (the representation: up to 38 passes per stage): the C x C x 9 weights in registers for all passes;
+     * else (one pass on a 7 x 7 map, four waves per SIMD on 128 registers) read as the chains consume them */
+    float wv[kHoist ? C * C * 9 : 1];
+    if constexpr (kHoist) {
+#pragma unroll
+        for (int j = 0; j < C * C * 9; ++j) wv[j] = cw[w_off + j];
+    }
+    const float inv_s = 1.0f / (float)S; /* r / S below: r < 2401, S <= 49, exact with the half offset */
+    for (int r0 = 0; r0 < n; r0 += kWave) {
+        const bool live = r0 + lane < n;
+        const int r = live ? r0 + lane : 0;
+        const int oy = (int)(((float)r + 0.5f) * inv_s), ox = r - oy * S;
+        const float* tp = pad + oy * P + ox; /* the window's top-left tap */
+        float tv[C * 9];
+#pragma unroll
+        for (int ci = 0; ci < C; ++ci) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) tv[ci * 9 + ky * 3 + kx] = tp[ci * np + ky * P + kx];
+            }
+        }
+#pragma unroll
+        for (int co = 0; co < C; ++co) {
+            float acc = 0.0f;
+#pragma unroll
+            for (int j = 0; j < C * 9; ++j) {
+                float w;
+                if constexpr (kHoist) w = wv[co * C * 9 + j];
+                else w = cw[w_off + co * C * 9 + j];
+                acc = mzs_fma(w, tv[j], acc);
+            }
+            if (live) out[co * n + r] = acc;
+        }
+    }
+    wave_sync();
+}
+
+/* out [CO][7][7] = relu(batchnorm(conv3x3(in [CI][7][7]))), stride 1, padding 1: the dynamics net's first
+ * stage (one pass: 49 pixels), a lane per pixel with its CI x 9 taps read once for all CO chains, as above */
+template <int CI, int CO>
+__device__ __forceinline__ void vis_conv3_bn(const float* cw, size_t w_off, const mzs_vis_bn& bn, const float* in,
+                                             float* out, int lane) {
+    constexpr int S = MZS_VIS_S4, n = S * S;
+    const bool live = lane < n;
+    const int r = live ? lane : 0;
+    const int oy = r / S, ox = r - oy * S;
+    float tv[CI * 9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int iy = oy + ky - 1, ix = ox + kx - 1;
+            const bool v = iy >= 0 && iy < S && ix >= 0 && ix < S;
+            const int off = v ? iy * S + ix : 0;
+#pragma unroll
+            for (int ci = 0; ci < CI; ++ci) {
+                const float x = in[ci * n + off];
+                tv[ci * 9 + ky * 3 + kx] = v ? x : 0.0f;
+            }
+        }
+    }
+#pragma unroll
+    for (int co = 0; co < CO; ++co) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < CI * 9; ++j) acc = mzs_fma(cw[w_off + co * CI * 9 + j], tv[j], acc);
+        const float g = cw[bn.w + co], var = cw[bn.var + co], mu = cw[bn.mean + co], be = cw[bn.b + co];
+        const float y = mzs_fma(acc - mu, g / __builtin_sqrtf(var + 1e-5f), be);
+        if (live) out[co * n + r] = y > 0.0f ? y : 0.0f;
+    }
+    wave_sync();
+}
+
 /* x += conv_a(R(conv_b(R(conv_a(R(x)))))), R = relu(batchnorm(.)); x [C][S][S]; t1, t2 scratch.  The block's
  * parameters sit at `base` of the cache in mzs_vis_res_layout's order (conv_a, conv_b, batchnorm): plain
  * scalars — offsets selected out of the layout structs ended up as indexed loads from scratch memory */
+template <bool kHoist = false>
 __device__ __forceinline__ void vis_res_block(const float* blob, size_t base, int C, float* x, int S, float* t1,
                                               float* t2, int lane) {
     const int n = S * S;
     const size_t cc9 = (size_t)C * C * 9;
     mzs_vis_bn bn;
     bn.w = base + 2 * cc9, bn.b = bn.w + C, bn.mean = bn.w + 2 * C, bn.var = bn.w + 3 * C;
-    /* one copy of the batchnorm + convolution code per block (a loop, not three inlined stages): the
-     * simulation loop has to fit the instruction cache */
+    /* one copy of the stage's code per block (a loop, not three inlined stages); t1 holds the map with its border */
     const float* src = x;
 #pragma nounroll
     for (int i = 0; i < 3; ++i) {
-        vis_bn_relu(blob, bn, src, C, n, t1, lane);
-        vis_conv3(blob + base + (i == 1 ? cc9 : 0), t1, C, S, C, 1, t2, lane);
+        const size_t w_off = base + (i == 1 ? cc9 : 0);
+        if (C == kVisC) {
+            vis_bn_relu_pad<kVisC>(blob, bn, src, S, t1, lane);
+            vis_conv3_pad<kVisC, kHoist>(blob, w_off, t1, S, t2, lane);
+        } else {
+            vis_bn_relu_pad<kVisC / 2>(blob, bn, src, S, t1, lane);
+            vis_conv3_pad<kVisC / 2, kHoist>(blob, w_off, t1, S, t2, lane);
+        }
         src = t2;
     }
     for (int i = lane; i < C * n; i += kWave) x[i] = t2[i] + x[i];
@@ -286,7 +419,7 @@ __device__ __forceinline__ void vis_representation(const Model& m, const WaveLds
     const mzs_vision_offsets o = vis_offsets(m);
     const float* blob = L.vc; /* every parameter of the representation is in the cache, at its blob offset */
     float *x = L.ob, *t1 = L.xa, *t2 = L.xb;
-    vis_conv3(blob + o.r_conv_in, obs_g, kVisC, MZS_VIS_SIDE, kVisC / 2, 2, x, lane); /* 1 x 49 x 49 */
+    vis_conv3_t<kVisC, 4>(blob + o.r_conv_in, obs_g, MZS_VIS_SIDE, kVisC / 2, 2, x, lane); /* 1 x 49 x 49 */
     /* the eight residual blocks through ONE copy of the block's code (the instruction cache again):
      * res_in x 2 | conv_out -> 3 x 25 x 25 | res_out x 2 | pool -> 13 x 13 | res_out x 3 | pool -> 7 x 7 | res */
 #pragma unroll
@@ -301,7 +434,7 @@ __device__ __forceinline__ void vis_representation(const Model& m, const WaveLds
         }
         const size_t base = blk < 2 ? o.r_res_in.conv_a : (blk == 7 ? o.r_res.conv_a : o.r_res_out.conv_a);
         const int S = blk < 2 ? MZS_VIS_S1 : (blk < 4 ? MZS_VIS_S2 : (blk < 7 ? MZS_VIS_S3 : MZS_VIS_S4));
-        vis_res_block(blob, base, blk < 2 ? kVisC / 2 : kVisC, x, S, t1, t2, lane);
+        vis_res_block<true>(blob, base, blk < 2 ? kVisC / 2 : kVisC, x, S, t1, t2, lane);
     }
     for (int i = lane; i < kVisHidden; i += kWave) {
         const float v = x[i];
@@ -322,8 +455,7 @@ __device__ __forceinline__ float vis_dynamics(const Model& m, const WaveLds& L, 
     for (int i = lane; i < kVisPix; i += kWave) L.xh[kVisHidden + i] = pv;
     wave_sync();
     const float* cw = L.vc;
-    vis_conv3(cw + o.d_conv, L.xh, kVisC + 1, MZS_VIS_S4, kVisC, 1, t1, lane);
-    vis_bn_relu(cw, o.d_bn, t1, kVisC, kVisPix, x, lane);
+    vis_conv3_bn<kVisC + 1, kVisC>(cw, o.d_conv, o.d_bn, L.xh, x, lane);
     for (int l = 0; l < m.L; ++l) vis_res_block(cw, o.d_res.conv_a, kVisC, x, MZS_VIS_S4, t1, t2, lane);
     vis_head_mlp<NB>(m, blob, cw, o.d_conv_rew, o.d_conv_rew_b, kVisC + 1, o.d_fc.in_w, m.Sd, L.xh, logits, t1, t2, lane);
     const float reward = seg_support_scalar(logits, m.Sd, lane);

@@ -929,7 +929,7 @@ LdsLayout make_lds_layout(const Model& m, int n_nodes, int S, bool vis_sims_only
             act = act > 256 ? act : 256;
             ob = 256 + 128;
         } else {
-            act = kVisBuf > act ? kVisBuf : act;
+            act = kVisPadBuf > act ? kVisPadBuf : act; /* xa holds the 49 x 49 map with its border */
             ob = kVisBuf;
         }
     }
