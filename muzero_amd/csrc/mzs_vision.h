@@ -311,48 +311,90 @@ __device__ __forceinline__ void vis_avgpool(const float* in, int C, int Si, floa
     wave_sync();
 }
 
-/* y = [relu](b + W x), contract "dot" (even / odd chains); Wt = W^T [nin][nout] (the transposed copy
- * mzs_set_weights makes: lanes read neighbouring addresses).  NB rows are requested ahead of the chains
- * that consume them (a trip to L2 per batch; NB = 64: three for the 147-wide layer, one for the others,
- * where batches of sixteen made ten and four; NB = 32 where four waves share a SIMD and 128 registers);
- * the last, partial batch reads clamped rows and skips them by a select. */
+/* The Linear layers' weights as the kernels read them: a store of its own (mzs_set_weights builds it, Model::w
+ * points at it) holding, head after head (0: reward, 1: value, 2: policy), the matrices in, mid (if L > 0), out,
+ * each from an offset that is a multiple of four floats.  A matrix W [nout][nin] is laid out in quads of rows of
+ * W^T: element (k, j), k < 4 (nin / 4), at ((k / 4) nout + j) 4 + k % 4 — lane j fetches four consecutive k with
+ * one 16-byte load, the 64 lanes of a load touch 1 KB of neighbouring addresses — and the last nin % 4 rows of
+ * W^T behind them as [k][j]. */
+__host__ __device__ inline size_t vis_r4(size_t n) { return (n + 3) & ~(size_t)3; }
+struct VisLin {
+    size_t in_w, mid_w, out_w;
+};
+__host__ __device__ inline size_t vis_lin_head_floats(int H, int L, int n_out) {
+    return vis_r4((size_t)H * MZS_VIS_HIDDEN) + (L > 0 ? vis_r4((size_t)H * H) : 0) + vis_r4((size_t)n_out * H);
+}
+__host__ __device__ inline VisLin vis_lin_offsets(int head, int H, int L, int Sd, int A) {
+    (void)A;
+    VisLin v;
+    v.in_w = (size_t)head * vis_lin_head_floats(H, L, Sd); /* heads 0 and 1 both end in Sd outputs */
+    v.mid_w = v.in_w + vis_r4((size_t)H * MZS_VIS_HIDDEN);
+    v.out_w = v.mid_w + (L > 0 ? vis_r4((size_t)H * H) : 0);
+    return v;
+}
+__host__ __device__ inline size_t vis_lin_total(int H, int L, int Sd, int A) {
+    return 2 * vis_lin_head_floats(H, L, Sd) + vis_lin_head_floats(H, L, A);
+}
+
+/* y = [relu](b + W x), contract "dot" (even / odd chains: rows 4q, 4q + 2 feed e, rows 4q + 1, 4q + 3 feed o);
+ * W in the quad layout above.  NB rows (NB / 4 loads of 16 bytes) are requested ahead of the chains that consume
+ * them (a trip to L2 per batch; NB = 64: three for the 147-wide layer, one for the others; NB = 32 where four
+ * waves share a SIMD and 128 registers); a partial last batch reads clamped quads and skips them by a select. */
 template <int NB>
-__device__ __forceinline__ void vis_linear(const float* __restrict__ Wt, const float* __restrict__ b, const float* x,
+__device__ __forceinline__ void vis_linear(const float* __restrict__ W, const float* __restrict__ b, const float* x,
                                            int nout, int nin, bool relu, float* y, int lane) {
-    constexpr int NT = 32;
+    constexpr int QB = NB / 4, QT = 8;
+    const int Q = nin >> 2;
     for (int j = lane; j < nout; j += kWave) {
-        const float* __restrict__ w = Wt + j;
+        const float4* __restrict__ wq = reinterpret_cast<const float4*>(W) + j;
         float e = b[j], o = 0.0f;
-        int k = 0;
-        for (; k + NB <= nin; k += NB) {
-            float wv[NB];
-            float4 xq[NB / 4];
+        int q = 0;
+        for (; q + QB <= Q; q += QB) {
+            float4 wv[QB], xq[QB];
 #pragma unroll
-            for (int u = 0; u < NB; ++u) wv[u] = w[(size_t)(k + u) * nout];
+            for (int u = 0; u < QB; ++u) wv[u] = wq[(size_t)(q + u) * nout];
 #pragma unroll
-            for (int u = 0; u < NB / 4; ++u) xq[u] = *reinterpret_cast<const float4*>(x + k + 4 * u);
+            for (int u = 0; u < QB; ++u) xq[u] = *reinterpret_cast<const float4*>(x + 4 * (q + u));
             __builtin_amdgcn_sched_barrier(0); /* every request of the batch leaves before the chains start */
 #pragma unroll
-            for (int u = 0; u < NB / 4; ++u) {
-                e = mzs_fma(wv[4 * u], xq[u].x, e);
-                o = mzs_fma(wv[4 * u + 1], xq[u].y, o);
-                e = mzs_fma(wv[4 * u + 2], xq[u].z, e);
-                o = mzs_fma(wv[4 * u + 3], xq[u].w, o);
+            for (int u = 0; u < QB; ++u) {
+                e = mzs_fma(wv[u].x, xq[u].x, e);
+                o = mzs_fma(wv[u].y, xq[u].y, o);
+                e = mzs_fma(wv[u].z, xq[u].z, e);
+                o = mzs_fma(wv[u].w, xq[u].w, o);
             }
         }
-        for (; k < nin; k += NT) { /* k is even here: even rows feed e, odd rows o, as above */
-            float wv[NT], xv[NT];
+        for (; q < Q; q += QT) {
+            float4 wv[QT], xq[QT];
 #pragma unroll
-            for (int u = 0; u < NT; ++u) {
-                const int kk = k + u < nin ? k + u : nin - 1;
-                wv[u] = w[(size_t)kk * nout], xv[u] = x[kk];
+            for (int u = 0; u < QT; ++u) {
+                const int qq = q + u < Q ? q + u : Q - 1;
+                wv[u] = wq[(size_t)qq * nout];
+                xq[u] = *reinterpret_cast<const float4*>(x + 4 * qq);
             }
 #pragma unroll
-            for (int u = 0; u < NT; u += 2) {
-                const float e2 = mzs_fma(wv[u], xv[u], e), o2 = mzs_fma(wv[u + 1], xv[u + 1], o);
-                e = k + u < nin ? e2 : e;
-                o = k + u + 1 < nin ? o2 : o;
+            for (int u = 0; u < QT; ++u) {
+                const float e2 = mzs_fma(wv[u].x, xq[u].x, e), o2 = mzs_fma(wv[u].y, xq[u].y, o);
+                const float e3 = mzs_fma(wv[u].z, xq[u].z, e2), o3 = mzs_fma(wv[u].w, xq[u].w, o2);
+                e = q + u < Q ? e3 : e;
+                o = q + u < Q ? o3 : o;
             }
+        }
+        /* the last nin % 4 rows: [k][j] behind the quads; row 4Q feeds e, 4Q + 1 o, 4Q + 2 e */
+        const int nt = nin - 4 * Q;
+        if (nt > 0) {
+            const float* __restrict__ wt = W + (size_t)4 * Q * nout + j;
+            float tw[3], tx[3];
+#pragma unroll
+            for (int u = 0; u < 3; ++u) {
+                const int uu = u < nt ? u : nt - 1;
+                tw[u] = wt[(size_t)uu * nout], tx[u] = x[4 * Q + uu];
+            }
+            const float e2 = mzs_fma(tw[0], tx[0], e), o2 = mzs_fma(tw[1], tx[1], o);
+            e = e2;
+            o = nt > 1 ? o2 : o;
+            const float e3 = mzs_fma(tw[2], tx[2], e);
+            e = nt > 2 ? e3 : e;
         }
         const float v = e + o;
         y[j] = relu && !(v > 0.0f) ? 0.0f : v;
@@ -364,7 +406,7 @@ __device__ __forceinline__ void vis_linear(const float* __restrict__ Wt, const f
  * cw: the cached parameters (conv_w, conv_b are blob offsets into them) */
 template <int NB>
 __device__ __forceinline__ void vis_head_mlp(const Model& m, const float* __restrict__ blob, const float* cw,
-                                             size_t conv_w, size_t conv_b, int Ci, size_t fc_base, int n_out,
+                                             size_t conv_w, size_t conv_b, int Ci, size_t fc_base, int head, int n_out,
                                              const float* x, float* logits, float* t1, float* t2, int lane) {
     constexpr int CM = kVisC + 1;
     for (int co = 0; co < kVisC; ++co) {
@@ -392,13 +434,14 @@ __device__ __forceinline__ void vis_head_mlp(const Model& m, const float* __rest
     const size_t out_w = mid_b + (m.L > 0 ? H : 0), out_b = out_w + (size_t)n_out * H;
     /* the 147-wide layer has a copy of vis_linear of its own (constant fan-in: its partial last batch is
      * resolved at compile time), the H-wide ones share the second */
-    vis_linear<NB>(m.w + fc_base, blob + in_b, t1, m.H, kVisHidden, true, t2, lane);
+    const VisLin lw = vis_lin_offsets(head, m.H, m.L, m.Sd, m.A); /* the weights: offsets into the quad store */
+    vis_linear<NB>(m.w + lw.in_w, blob + in_b, t1, m.H, kVisHidden, true, t2, lane);
     const float* src = t2;
     float* dst = t1;
 #pragma nounroll
     for (int l = 1; l < m.L + 2; ++l) {
         const bool last = l == m.L + 1;
-        vis_linear<NB>(m.w + (last ? out_w : mid_w), blob + (last ? out_b : mid_b), src, last ? n_out : m.H, m.H, !last,
+        vis_linear<NB>(m.w + (last ? lw.out_w : lw.mid_w), blob + (last ? out_b : mid_b), src, last ? n_out : m.H, m.H, !last,
                    last ? logits : dst, lane);
         float* t = const_cast<float*>(src);
         src = dst;
@@ -457,7 +500,7 @@ __device__ __forceinline__ float vis_dynamics(const Model& m, const WaveLds& L, 
     const float* cw = L.vc;
     vis_conv3_bn<kVisC + 1, kVisC>(cw, o.d_conv, o.d_bn, L.xh, x, lane);
     for (int l = 0; l < m.L; ++l) vis_res_block(cw, o.d_res.conv_a, kVisC, x, MZS_VIS_S4, t1, t2, lane);
-    vis_head_mlp<NB>(m, blob, cw, o.d_conv_rew, o.d_conv_rew_b, kVisC + 1, o.d_fc.in_w, m.Sd, L.xh, logits, t1, t2, lane);
+    vis_head_mlp<NB>(m, blob, cw, o.d_conv_rew, o.d_conv_rew_b, kVisC + 1, o.d_fc.in_w, 0, m.Sd, L.xh, logits, t1, t2, lane);
     const float reward = seg_support_scalar(logits, m.Sd, lane);
     for (int i = lane; i < kVisHidden; i += kWave) {
         const float v = x[i] > 0.0f ? x[i] : 0.0f; /* the Sequential's closing ReLU (:215) */
@@ -483,7 +526,7 @@ __device__ __forceinline__ float vis_prediction(const Model& m, const WaveLds& L
 #pragma nounroll
     for (int hd = 0; hd < 2; ++hd) { /* value head, then policy head: one copy of the head's code */
         const size_t cv = (hd ? o.p_conv_pol : o.p_conv_val) - dl, cb = (hd ? o.p_conv_pol_b : o.p_conv_val_b) - dl;
-        vis_head_mlp<NB>(m, blob, cw, cv, cb, kVisC, hd ? o.p_p.in_w : o.p_v.in_w, hd ? m.A : m.Sd, x, logits, t1, t2, lane);
+        vis_head_mlp<NB>(m, blob, cw, cv, cb, kVisC, hd ? o.p_p.in_w : o.p_v.in_w, 1 + hd, hd ? m.A : m.Sd, x, logits, t1, t2, lane);
         if (hd == 0) {
             value = seg_support_scalar(logits, m.Sd, lane);
             wave_sync();

@@ -1347,7 +1347,8 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     StoreBuilder sb;
     describe_model(d, &h->model, &sb);
     h->w_floats = sb.data.size();
-    if (d.model_kind == MZS_MODEL_VISION) h->w_floats = mzs_blob_total(&d); /* the blob with its Linear weights transposed */
+    if (d.model_kind == MZS_MODEL_VISION) /* the Linear layers' quad store (mzs_vision.h) */
+        h->w_floats = vis_lin_total(d.hidden_dim, d.n_mid_layers, d.state_dim, d.n_actions);
     h->n_nodes_max = mzs_nodes_per_game(d.n_actions, cfg->max_simulations);
     h->lds = make_lds_layout(h->model, h->n_nodes_max, cfg->max_simulations, d.model_kind == MZS_MODEL_VISION);
     if (waves_per_block(h->lds) == 0) {
@@ -1440,22 +1441,31 @@ int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats) {
     const int H = d.hidden_dim, Sd = d.state_dim, A = d.n_actions, ob = d.obs_dim;
     if (d.model_kind == MZS_MODEL_VISION) {
         /* convolutions, batchnorms and biases are read from the blob in place; the Linear layers of the three
-         * head MLPs from a second copy in which every weight matrix [n_out][n_in] is stored transposed (same
-         * offsets): lane j of a wave then reads W^T[k][j] — neighbouring addresses — where the torch layout
-         * would make the 64 lanes of a load touch 64 cache lines */
+         * head MLPs from a store of their own, laid out for 16-byte loads (mzs_vision.h, vis_lin_offsets) */
         HIP_TRY(hipMemcpy(h->blob_dev, B, n_floats * sizeof(float), hipMemcpyHostToDevice));
-        std::vector<float> t(host);
+        /* the quad store of mzs_vision.h (vis_lin_offsets) */
+        std::vector<float> t(vis_lin_total(H, d.n_mid_layers, Sd, A), 0.0f);
         const mzs_vision_offsets vo = mzs_vision_layout(&d);
-        const auto transpose = [&](size_t off, int n_out, int n_in) {
+        const auto quads = [&](size_t dst, size_t src, int n_out, int n_in) {
+            const int Q = n_in / 4;
             for (int j = 0; j < n_out; ++j)
-                for (int k = 0; k < n_in; ++k) t[off + (size_t)k * n_out + j] = B[off + (size_t)j * n_in + k];
+                for (int k = 0; k < n_in; ++k) {
+                    const float v = B[src + (size_t)j * n_in + k];
+                    if (k < 4 * Q)
+                        t[dst + ((size_t)(k / 4) * n_out + j) * 4 + k % 4] = v;
+                    else
+                        t[dst + (size_t)4 * Q * n_out + (size_t)(k - 4 * Q) * n_out + j] = v;
+                }
         };
-        for (const mzs_vis_mlp* fc : {&vo.d_fc, &vo.p_v, &vo.p_p}) {
-            transpose(fc->in_w, H, MZS_VIS_HIDDEN);
-            if (d.n_mid_layers > 0) transpose(fc->mid_w, H, H);
-            transpose(fc->out_w, fc->n_out, H);
+        const mzs_vis_mlp* heads[3] = {&vo.d_fc, &vo.p_v, &vo.p_p};
+        for (int hd = 0; hd < 3; ++hd) {
+            const mzs_vis_mlp* fc = heads[hd];
+            const VisLin lw = vis_lin_offsets(hd, H, d.n_mid_layers, Sd, A);
+            quads(lw.in_w, fc->in_w, H, MZS_VIS_HIDDEN);
+            if (d.n_mid_layers > 0) quads(lw.mid_w, fc->mid_w, H, H);
+            quads(lw.out_w, fc->out_w, fc->n_out, H);
         }
-        HIP_TRY(hipMemcpy(h->w_dev, t.data(), n_floats * sizeof(float), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(h->w_dev, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
         h->have_weights = true;
         return MZS_OK;
     }
