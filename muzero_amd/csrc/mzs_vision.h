@@ -15,9 +15,11 @@
  *
  * Channel counts are 1..4 and the maps 49 x 49 down to 7 x 7: HBM- and latency-bound work with K =
  * 9..36 per output, nothing for MFMA.  Lanes own output pixels; every map lives in the wave's LDS
- * slice (three buffers of 49 x 49 floats for the representation, 7 x 7 x 4 afterwards), and so does a copy
- * of every convolution's and batchnorm's parameters (vis_cache_load, once per kernel); the Linear layers
- * of the head MLPs stream their weights from the transposed copy in global memory.
+ * slice (three buffers of 49 x 49 floats — one with a border — for the representation, 7 x 7 x 4 afterwards),
+ * and so does a copy of every convolution's and batchnorm's parameters (vis_cache_load, once per kernel);
+ * the Linear layers of the head MLPs stream their weights from a store laid out for 16-byte loads
+ * (vis_lin_offsets) in global memory.  A search runs the roots in k_inference (representation: one wave per
+ * SIMD for its LDS) and the simulations in k_search_fused (dynamics + prediction: up to four waves per SIMD).
  */
 #ifndef MZS_VISION_H
 #define MZS_VISION_H
@@ -128,21 +130,6 @@ __device__ __forceinline__ void vis_conv3(const float* w, const float* in, int C
         case 3: vis_conv3_t<3>(w, in, Si, Co, s, out, lane); return;
         default: vis_conv3_t<4>(w, in, Si, Co, s, out, lane); return;
     }
-}
-
-/* out = relu(batchnorm(in)) on [C][n], eval mode; cw: the cached parameters.  gamma / sqrt(var + eps)
- * once per channel — the same value as once per element */
-__device__ __forceinline__ void vis_bn_relu(const float* cw, const mzs_vis_bn& bn, const float* in, int C, int n,
-                                            float* out, int lane) {
-    for (int c = 0; c < C; ++c) {
-        const float g = cw[bn.w + c], var = cw[bn.var + c], mu = cw[bn.mean + c], be = cw[bn.b + c];
-        const float iv = g / __builtin_sqrtf(var + 1e-5f);
-        for (int i = lane; i < n; i += kWave) {
-            const float y = mzs_fma(in[c * n + i] - mu, iv, be);
-            out[c * n + i] = y > 0.0f ? y : 0.0f;
-        }
-    }
-    wave_sync();
 }
 
 /* A residual block's stage, conv3x3(relu(batchnorm(in))) with C -> C channels, in two passes over a map with
