@@ -110,6 +110,57 @@ def test_vision_search_many_games_equals_oracle():
     eng.close()
 
 
+@pytest.mark.parametrize("A,Sd,H,L", [(3, 17, 70, 1), (2, 9, 30, 2), (5, 31, 130, 1)])
+def test_vision_odd_head_shapes_equal_oracle(A, Sd, H, L):
+    """Head MLPs whose width is neither a multiple of four (the weight store's last rows behind the quads)
+    nor within one wavefront (several passes over the outputs), three to five actions: inference and a short
+    search on seeded random weights == oracle, bit for bit (no reference run of these shapes: parity vs the
+    oracle only, which tests/test_vision_oracle.py pins to the reference on the fixture shapes)."""
+    from muzero_amd.engine import SearchEngine
+    from muzero_amd.model import vision_blob_layout
+    from oracle import mz_oracle as mzo
+    rs = np.random.RandomState(A * 1000 + H)
+    parts = []
+    for name, shp in vision_blob_layout(A, Sd, H, L):
+        n = int(np.prod(shp))
+        if name.endswith("bn_var"):
+            v = rs.uniform(0.5, 1.5, n)
+        elif name.endswith("bn_w"):
+            v = rs.uniform(0.8, 1.2, n)
+        elif "conv" in name and not name.endswith("_b"):
+            v = rs.standard_normal(n) * 0.35
+        else:
+            v = rs.standard_normal(n) * (1.0 / np.sqrt(max(shp[-1], 1)) if len(shp) == 2 else 0.1)
+        parts.append(v.astype(np.float32))
+    blob = np.concatenate(parts)
+    d = mzo.dims(98, A, Sd, H, L, 2)
+    G, S = 7, 9
+    obs = rs.uniform(0.0, 1.0, size=(G, 3, 98, 98)).astype(np.float32)
+    eng = SearchEngine((98, A, Sd, H, L, 2), max_games=G, max_simulations=S, discount=0.997)
+    eng.set_weights(blob)
+    hid, pol, val = [t.cpu().numpy() for t in eng.initial_inference(obs)]
+    oh = mzo.representation(d, blob, obs)
+    op, ov = mzo.prediction(d, blob, oh)
+    assert np.array_equal(bits(hid), bits(oh)) and np.array_equal(bits(pol), bits(op))
+    assert np.array_equal(bits(val), bits(ov)) and np.isfinite(ov).all()
+    act = (np.arange(G) % A).astype(np.int32)
+    rew, nh, pol, val = [t.cpu().numpy() for t in eng.recurrent_inference(oh, act)]
+    orew, onh = mzo.dynamics(d, blob, oh, act)
+    op, ov = mzo.prediction(d, blob, onh)
+    assert np.array_equal(bits(rew), bits(orew)) and np.array_equal(bits(nh), bits(onh))
+    assert np.array_equal(bits(pol), bits(op)) and np.array_equal(bits(val), bits(ov))
+    seeds = np.arange(G, dtype=np.int64) + 5
+    eng.search_streams(obs, seeds, S, True)
+    out = eng.results_host()
+    dirichlet, noise = eng.fill_streams(seeds, S, True)
+    ref = mzo.search(d, blob, S, 0.997, 0.25, eng.pbc, obs=obs, dirichlet=dirichlet.cpu().numpy(),
+                     noise=noise.cpu().numpy(), train=True, want=("visits", "root_value", "consumed"))
+    assert np.array_equal(out["visits"], ref["visits"])
+    assert np.array_equal(bits(out["root_value"]), bits(ref["root_value"]))
+    assert np.array_equal(out["consumed"], ref["consumed"])
+    eng.close()
+
+
 def test_vision_muzero_drop_in():
     """Muzero(model_structure='vision_model'): the reference's wrapper surface (muzero_model.py:828-905)
     — (1, 3, 98, 98) observations, (1, 3, 7, 7) hidden states — against the reference's own outputs, a
