@@ -27,7 +27,32 @@ SHAPES = [
     # oracle restates the same contract)
     (4, 2, 31, 64, 0, 0, 1), (8, 4, 31, 64, 0, 0, 1), (4, 2, 31, 64, 2, 0, 1), (8, 4, 31, 64, 1, 0, 1),
     (5, 7, 19, 24, 1, 0, 1),
+    # vision_model (kind 2: obs_dim = the image side): two launches per search (roots, simulations); small game
+    # counts, the oracle's ResNet runs on the host
+    (98, 2, 31, 64, 1, 2), (98, 4, 21, 32, 2, 2), (98, 3, 17, 70, 1, 2),
 ]
+
+
+def random_blob(rs, shape, scale):
+    """Seeded random weights of a shape; vision_model: positive batchnorm variances, gains near 1."""
+    from muzero_amd.model import blob_layout, vision_blob_layout
+    obs_dim, A, Sd, H, L, kind = shape[:6]
+    if kind != 2:
+        n_w = sum(int(np.prod(shp)) for _, shp in blob_layout(obs_dim, A, Sd, H, L, kind))
+        return (rs.standard_normal(n_w) * scale).astype(np.float32)
+    parts = []
+    for name, shp in vision_blob_layout(A, Sd, H, L):
+        n = int(np.prod(shp))
+        if name.endswith("bn_var"):
+            v = rs.uniform(0.5, 1.5, n)
+        elif name.endswith("bn_w"):
+            v = rs.uniform(0.8, 1.2, n)
+        elif "conv" in name and not name.endswith("_b"):
+            v = rs.standard_normal(n) * 0.35
+        else:
+            v = rs.standard_normal(n) * (1.0 / np.sqrt(max(shp[-1], 1)) if len(shp) == 2 else 0.1)
+        parts.append(v.astype(np.float32))
+    return np.concatenate(parts)
 
 
 def run(seconds, seed=0, threads=16, max_games=4096, log=print):
@@ -53,11 +78,13 @@ def run(seconds, seed=0, threads=16, max_games=4096, log=print):
         G = int(rs.choice([1, 3, 17, 64, 255, 1024, a.max_games, a.max_games, 2 * a.max_games + 37]))
         if A > 8:
             G = min(G, 255)
+        if kind == 2:
+            G, S = min(G, int(rs.choice([1, 5, 17, 40]))), min(S, 25)
         train = bool(rs.randint(4) != 0)
         d = mzo.dims(obs_dim, A, Sd, H, L, kind, prec)
-        n_w = sum(int(np.prod(shp)) for _, shp in blob_layout(obs_dim, A, Sd, H, L, kind))
-        blob = (rs.standard_normal(n_w) * scale).astype(np.float32)
-        obs = rs.uniform(-1, 1, size=(G, obs_dim)).astype(np.float32)
+        blob = random_blob(rs, shape, scale)
+        obs = (rs.uniform(0, 1, size=(G, 3, obs_dim, obs_dim)) if kind == 2
+               else rs.uniform(-1, 1, size=(G, obs_dim))).astype(np.float32)
         seeds = rs.randint(0, 2 ** 31 - 1, size=G).astype(np.int64)
         eng = SearchEngine(shape, max_games=G, max_simulations=S, discount=0.997)
         eng.set_weights(blob)
