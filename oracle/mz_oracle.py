@@ -40,9 +40,15 @@ class SearchOut(C.Structure):
 
 
 def build(force=False):
+    """Path of the oracle library, (re)built when a source is newer.  MZO_ORACLE_SO names another build of
+    the same sources (the sanitizer build of tests/test_oracle_golden.py::test_oracle_sanitized)."""
+    override = os.environ.get("MZO_ORACLE_SO")
+    if override:
+        return override
     so = os.path.join(_HERE, "libmzoracle.so")
     srcs = [os.path.join(_HERE, f) for f in ("mz_oracle.c", "mz_train_oracle.c", "mz_selfplay_oracle.c",
-                                             "mz_oracle.h", "../include/mzs_env.h")]
+                                             "mz_vision_oracle.c", "mz_oracle.h", "../include/mzs_env.h",
+                                             "../include/mzs_numeric.h", "../include/mzs_layout.h")]
     stale = os.path.exists(so) and all(os.path.exists(f) for f in srcs) and \
         os.path.getmtime(so) < max(os.path.getmtime(f) for f in srcs)
     if force or stale or not os.path.exists(so):

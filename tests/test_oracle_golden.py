@@ -184,3 +184,38 @@ def test_oracle_threads_agree():
     b = mzo.search(d, blob, 11, 0.997, 0.25, fx["pbc_table"], n_threads=4, **kw)
     for k in a:
         assert np.array_equal(a[k], b[k])
+
+
+def test_oracle_sanitized():
+    """the CPU restatement under -fsanitize=address,undefined.  Builds
+    oracle/libmzoracle_san.so and runs the oracle pin tests (search, model, training, self-play, vision,
+    bf16) in a child interpreter that preloads the sanitizer runtimes; any report aborts the child."""
+    import shutil
+    import subprocess
+    import sys
+    if os.environ.get("MZO_ORACLE_SO"):
+        pytest.skip("already inside the sanitized child")
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("no gcc")
+    rts = []
+    for name in ("libasan.so", "libubsan.so"):
+        path = subprocess.check_output([gcc, f"-print-file-name={name}"], text=True).strip()
+        if not os.path.isabs(path) or not os.path.exists(path):
+            pytest.skip(f"{name} not installed")
+        rts.append(os.path.realpath(path))
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    odir = os.path.join(root, "oracle")
+    subprocess.check_call(["make", "-C", odir, "libmzoracle_san.so"], stdout=subprocess.DEVNULL)
+    env = dict(os.environ)
+    env.update(MZO_ORACLE_SO=os.path.join(odir, "libmzoracle_san.so"), LD_PRELOAD=":".join(rts),
+               ASAN_OPTIONS="detect_leaks=0:abort_on_error=1", UBSAN_OPTIONS="halt_on_error=1:print_stacktrace=1",
+               OMP_NUM_THREADS="2")
+    files = ["test_oracle_golden.py", "test_train_oracle.py", "test_selfplay_oracle.py", "test_vision_oracle.py",
+             "test_bf16_oracle.py"]
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "not gpu", "-p", "no:cacheprovider"]
+                       + [os.path.join(root, "tests", f) for f in files],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-3000:]
+    assert r.returncode == 0, tail
+    assert "passed" in r.stdout and "ERROR: AddressSanitizer" not in tail and "runtime error" not in tail, tail
