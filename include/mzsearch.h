@@ -232,8 +232,10 @@ int mzs_train_grad_static(mzs_handle* h, int32_t batch, int32_t unroll_steps, co
  * (init_criterion_and_optimizer, muzero_model.py:350-403; Loss_function, neural_network_mlp_model.py:
  * 236-262, always on softmax(logits) + 1e-9): 'general' = CE / CE (the default), 'general_kkc' =
  * KL / KL (log(target + 1e-9): NaN for negative targets, as in the reference), 'game' = MSE / ZERO,
- * 'game_mmc' = MSE / MSE.  The policy term is the cross-entropy in all of them.  Applies to every later
- * mzs_train_grad / mzs_train_grad_static on the handle. */
+ * 'game_mmc' = MSE / MSE.  The policy term is the cross-entropy in all of them; with a KL value criterion
+ * ('general_kkc', whose policy criterion carries label = ["zero_clamp_transform"], muzero_model.py:373-375)
+ * it is taken against target + 1e-9 like the reference's.  Applies to every later mzs_train_grad /
+ * mzs_train_grad_static on the handle. */
 #define MZS_LOSS_CE 0
 #define MZS_LOSS_KL 1
 #define MZS_LOSS_MSE 2

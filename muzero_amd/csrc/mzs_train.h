@@ -191,6 +191,14 @@ __device__ __forceinline__ void train_support_target(float x, int S, int* idx, f
  *   MSE mean (p - q)^2, c = -2 (p - q) / n          ZERO 0, c = 0
  * and dloss/dz = s (c - sum c s).  Returns the loss (uniform); *softmax_out = this lane's softmax
  * probability. */
+/* criterion of the policy term: always the cross-entropy, against p + 1e-9 when the loss type is
+ * 'general_kkc' (label = ["zero_clamp_transform"], muzero_model.py:373-375) — the one loss type whose
+ * value criterion is the KL divergence, which is how the kernels recognise it */
+constexpr int kLossCeClamped = 100;
+__device__ __forceinline__ int train_policy_mode(int loss_value) {
+    return loss_value == MZS_LOSS_KL ? kLossCeClamped : MZS_LOSS_CE;
+}
+
 __device__ __forceinline__ float train_ce(const float* z, int n, float p, float upstream, float* dz,
                                           float* softmax_out, int lane, int mode = MZS_LOSS_CE) {
     const bool valid = lane < n;
@@ -202,9 +210,10 @@ __device__ __forceinline__ float train_ce(const float* z, int n, float p, float 
     const float q = s + 1e-9f;
     const float pv = valid ? p : 0.0f;
     float c, term;
-    if (mode == MZS_LOSS_CE) {
-        c = -pv / q;
-        term = -pv * logf(q);
+    if (mode == MZS_LOSS_CE || mode == kLossCeClamped) {
+        const float pc = mode == kLossCeClamped ? pv + 1e-9f : pv;
+        c = -pc / q;
+        term = -pc * logf(q);
     } else if (mode == MZS_LOSS_KL) {
         const float pp = pv + 1e-9f;
         c = -pp / q;
@@ -316,7 +325,7 @@ __global__ void __launch_bounds__(64) k_train_sample(const TrainParams p) {
             if (lane == 0) p.priority[(size_t)k * B + b] = fabsf(mzs_inverse_value_transform(y) - tvk);
         }
         const float ptar = lane < A ? p.tp[((size_t)k * B + b) * A + lane] : 0.0f;
-        const float lp = train_ce(P + t.p_out, A, ptar, gs, P + t.p_dpol, &sm, lane);
+        const float lp = train_ce(P + t.p_out, A, ptar, gs, P + t.p_dpol, &sm, lane, train_policy_mode(p.loss_value));
         if (lane == 0) {
             p.loss_buf[(size_t)b * n_terms + t0] = lv;
             p.loss_buf[(size_t)b * n_terms + t0 + 1] = lp;

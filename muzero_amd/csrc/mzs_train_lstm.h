@@ -497,7 +497,8 @@ __global__ void __launch_bounds__(kLstmTrainThreads) k_lstm_heads(const LstmTrai
         float sm;
         if (hd == kHeadPol) {
             const float ptar = lane < A ? p.tp[((size_t)kt * B + t) * A + lane] : 0.0f;
-            const float lp = train_ce(out + (size_t)t * A, A, ptar, gs, dout + (size_t)t * A, &sm, lane);
+            const float lp = train_ce(out + (size_t)t * A, A, ptar, gs, dout + (size_t)t * A, &sm, lane,
+                                      train_policy_mode(p.loss_value));
             if (lane == 0) p.loss_buf[(size_t)t * n_terms + t0 + 1] = lp;
         } else {
             const float target = hd == kHeadVal ? p.tv[(size_t)kt * B + t] : p.tr[(size_t)kt * B + t];

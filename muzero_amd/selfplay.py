@@ -650,6 +650,11 @@ class SelfPlay:
                     raise ValueError("rolling rounds need n_rows to be a multiple of games_per_iteration")
                 a.begin(0, seeds, 0)
                 self.queued = 1
+            if self.queued == k:
+                # this round was never handed to the arena: the previous call was a last iteration
+                # (next_temperature=None), and learning_cycle / play is now called again
+                a.enqueue(seeds, k, temperature)
+                self.queued += 1
             if next_temperature is not None and self.queued == k + 1:
                 a.enqueue(seeds, k + 1, next_temperature)
                 self.queued += 1
@@ -657,6 +662,10 @@ class SelfPlay:
             # (mzs_arena_begin); every queued game carries its own
             moves, st, ev = play_until(self.eng, a, (k + 1) * N, self.S, temperature)
             self.lockstep_moves = moves
+            if st is None or st["done_upto"] < (k + 1) * N:
+                raise RuntimeError(f"rolling self-play: round {k} incomplete (games below row "
+                                   f"{0 if st is None else st['done_upto']} of {(k + 1) * N} finished, "
+                                   f"{self.queued} rounds queued): nothing saved")
             # The host now saves this round (device->host copies, NumPy bookkeeping).  Its rows were
             # complete when `ev` fired; the chunks play_until left in flight are already playing the
             # next round's games on the main stream.  Read the rows on a side stream that waits for

@@ -7,9 +7,10 @@ Device work (muzero_amd/csrc/mzs_train.h through the C-ABI): forward, losses, ba
 weight gradients, optimizer.
 
 Data parallelism: one process per GPU; every rank runs `mzs_train_grad` on its shard of the
-batch with `inv_global_batch = 1 / global batch size`, the flat fp32 gradient (12 734 floats
-for the CartPole MLP) is summed with ONE `all_reduce` (RCCL over xGMI under the "nccl"
-backend, gloo in the CPU tests) and every rank applies the same optimizer step, so replicas
+batch with `inv_global_batch = 1 / global batch size`, the flat fp32 bucket (the gradient, 12 734
+floats for the CartPole MLP, with the 3K loss scalars behind it) is summed with ONE `all_reduce`
+(RCCL over xGMI under the "nccl" backend, gloo in the CPU tests) and every rank applies the same
+optimizer step, so replicas
 that start identical stay bit-identical.  They start identical because Trainer broadcasts rank
 0's weights once at construction (every process draws its initial weights from its own torch
 generator; shard.broadcast_blob).
@@ -31,8 +32,8 @@ def _one_cycle(max_lr, total_steps, step):
     Defaults: pct_start 0.3, cosine annealing, div_factor 25, final_div_factor 1e4, momentum cycled
     0.95 -> 0.85 -> 0.95 (Adam: beta1), two phases."""
     total = int(total_steps)
-    if step >= total:
-        raise ValueError(f"Tried to step {step + 1} times. The specified number of total steps is {total}")
+    if step > total:                 # torch raises when step_num > total_steps (the step AT total still exists)
+        raise ValueError(f"Tried to step {step} times. The specified number of total steps is {total}")
     initial, base_m, max_m = max_lr / 25.0, 0.85, 0.95
     phases = ((0.3 * total - 1.0, initial, max_lr, max_m, base_m),
               (total - 1.0, max_lr, initial / 1e4, base_m, max_m))
@@ -99,15 +100,24 @@ def reshape_batch(batches, obs_dim, n_actions, unroll_steps):
     return obs, actions, tv, tr, tp, (None if ratio.size == 1 else ratio), game_pos
 
 
-def allreduce_gradient(grad, loss, group=None):
-    """The only collective of the training path: SUM the flat gradient bucket (and the small loss
-    vector) over the data-parallel ranks, in place.  No-op for one rank / no process group."""
+def allreduce_gradient(bucket, group=None):
+    """The only collective of the training path: ONE all_reduce(SUM) over the data-parallel ranks, in
+    place, of the flat bucket = the gradient followed by the 3K loss scalars (Trainer.bucket: both are
+    views into it).  No-op for one rank / no process group.  Returns the world size."""
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 1
-    dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=group)
-    dist.all_reduce(loss, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=group)
     return dist.get_world_size(group)
+
+
+def make_bucket(n_weights, unroll_steps, device=None):
+    """(bucket, grad view, loss view): the gradient (n_weights floats, padded to a 256-byte boundary)
+    and behind it the 3K loss scalars, in one allocation so that a step is one collective."""
+    n, k3 = int(n_weights), 3 * int(unroll_steps)
+    pad = -(-n // 64) * 64
+    bucket = torch.zeros(pad + k3, dtype=torch.float32, device=device)
+    return bucket, bucket[:n], bucket[pad:pad + k3]
 
 
 # loss_type (init_criterion_and_optimizer, muzero_model.py:350-403) -> the criteria of the value and reward
@@ -135,19 +145,30 @@ class Trainer:
         self.loss_type = loss_type
         _lib.check(self.lib.mzs_train_set_loss(engine.h, *LOSS_TYPES[loss_type]), "mzs_train_set_loss")
         dev, n = engine.device, engine.weight_count()
-        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.loss = torch.zeros(3 * self.K, dtype=torch.float32, device=dev)
+        self.bucket, self.grad, self.loss = make_bucket(n, self.K, dev)
         self.priority = torch.zeros((self.K, self.max_batch), dtype=torch.float32, device=dev)
+        self._sync_pending = False
         self.sync_replicas()
 
     def sync_replicas(self):
         """One broadcast of rank 0's weights (no-op for one rank): the all-reduced gradient step
-        keeps replicas identical only from an identical start."""
+        keeps replicas identical only from an identical start.  The decision is the same on every
+        rank: if no rank's engine has weights yet the broadcast is deferred to the first step() (which
+        raises if there are still none); ranks that disagree raise here, on all of them."""
         import torch.distributed as dist
-        if (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-                and self.eng.has_weights):
-            from . import shard
-            dev = self.eng.device if dist.get_backend() == "nccl" else None
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        from . import shard
+        dev = self.eng.device if dist.get_backend() == "nccl" else None
+        hw = 1.0 if self.eng.has_weights else 0.0
+        flag = torch.tensor([hw, -hw], dtype=torch.float32, device=dev or "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        any_has, all_have = float(flag[0]) > 0.5, float(flag[1]) < -0.5
+        if any_has != all_have:
+            raise RuntimeError("data-parallel Trainer: some ranks' engines have weights and some do not "
+                               "(call engine.set_weights on every rank, or on none, before building the Trainer)")
+        self._sync_pending = not all_have
+        if all_have:
             self.eng.set_weights(shard.broadcast_blob(self.weights(), dev))
 
     def current_lr(self):
@@ -181,6 +202,11 @@ class Trainer:
         _lib.check(self.lib.mzs_train_apply(e.h, C.c_void_p(self.grad.data_ptr()), OPTIMIZERS[self.opt],
                                             C.c_double(self.current_lr()), e._stream()), "mzs_train_apply")
         self.count += 1
+        if self.sch == "onecyclelr" and self.count - 1 > int(self.epoch):
+            # torch's OneCycleLR: optimizer.step() has run, then scheduler.step(epoch=count) raises
+            # (muzero_model.py:764-786) — same state, same error, same moment
+            raise ValueError(f"Tried to step {self.count - 1} times. The specified number of total steps is "
+                             f"{int(self.epoch)}")
 
     def step(self, obs, actions, tv, tr, tp, is_ratio=None, group=None):
         """One data-parallel training step.  With torch.distributed initialised every rank passes its
@@ -188,8 +214,12 @@ class Trainer:
         import torch.distributed as dist
         world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         B = np.shape(obs)[0] if not torch.is_tensor(obs) else obs.shape[0]
+        if self._sync_pending:                       # weights arrived after construction: broadcast them now
+            if not self.eng.has_weights:
+                raise RuntimeError("Trainer.step: the engine has no weights (engine.set_weights)")
+            self.sync_replicas()
         prio = self.grad_step(obs, actions, tv, tr, tp, is_ratio, global_batch=B * world)
-        allreduce_gradient(self.grad, self.loss, group)                      # one flat bucket
+        allreduce_gradient(self.bucket, group)                               # one flat bucket, one collective
         self.apply()
         return prio
 

@@ -180,8 +180,13 @@ static float loss_term(int mode, const float* z, int n, const float* p, float up
         }
     return (float)loss;
 }
+/* the policy term: cross-entropy, against p + 1e-9 under 'general_kkc' (label = ["zero_clamp_transform"],
+ * muzero_model.py:373-375; the one loss type whose value criterion is the KL divergence) */
 static float ce_loss(const float* z, int n, const float* p, float upstream, float* gz, float* s) {
-    return loss_term(MZO_LOSS_CE, z, n, p, upstream, gz, s);
+    if (g_loss_value != MZO_LOSS_KL) return loss_term(MZO_LOSS_CE, z, n, p, upstream, gz, s);
+    float pc[64];
+    for (int i = 0; i < n; ++i) pc[i] = p[i] + 1e-9f;
+    return loss_term(MZO_LOSS_CE, z, n, pc, upstream, gz, s);
 }
 
 /* ================================================================== 'lstm_model' ==========

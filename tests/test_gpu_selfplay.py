@@ -242,6 +242,33 @@ def test_rolling_learning_cycle_keeps_slots_busy():
     assert util[True] > util[False] + 0.05 and util[True] > 0.8
 
 
+def test_rolling_learning_cycle_called_twice():
+    """A second learning_cycle (or play) after a rolling run whose last iteration queued nothing ahead: the
+    round is handed to the arena then, every saved row is a finished game of THAT round, and the store's
+    lengths are the arena's."""
+    from muzero_amd.selfplay import Arena, ReplayStore, SelfPlay
+    from muzero_amd.train import Trainer
+    G, T, S, B, K, td, N = 64, 40, 8, 32, 3, 5, 160
+    eng, dims, blob = make_engine(G, S)
+    tr = Trainer(eng, K, B, "adam", 1e-3)
+    store = ReplayStore(window_size=3 * N, batch_size=B, num_unroll=K, td_steps=td, discount=0.997)
+    ar = Arena(eng, G, 6 * N, T)
+    np.random.seed(1)
+    loop = SelfPlay(None, eng, tr, ar, store, S, games_per_iteration=N, seed=7, rolling=True)
+    r1, _ = loop.learning_cycle(2, 1)
+    assert loop.episode == 2 and loop.queued == 2
+    r2, _ = loop.learning_cycle(2, 1)                       # round 2 was never queued by the first call
+    r3 = loop.play(1.0)                                     # and a bare play() after that
+    assert loop.episode == 5 and loop.queued == 5
+    assert all(1 <= x <= T for x in r1 + r2) and np.all(r3 >= 1)
+    length = host(ar.arrays["length"])
+    assert np.all(length[:5 * N] >= 1) and np.all(length[5 * N:] == 0)
+    assert len(store) == 3 * N + 1
+    assert all(length[r] == n for r, n in zip(store.rows, store.lengths))
+    assert ar.queue_state()[2] == 5 * N
+    ar.close(), eng.close()
+
+
 @pytest.mark.parametrize("temperature", [0.0, 1.0])
 def test_arena_step_zero_simulations(temperature):
     """number_of_mcts_simulation = 0 (experiment_130..133 configs): policy_step gets the root priors

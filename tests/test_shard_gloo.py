@@ -83,8 +83,14 @@ B = fx["s0_obs"].shape[0]; n = B // world; sl = slice(rank * n, (rank + 1) * n)
 out = mzo.train_grad(d, fx["blob0"], fx["s0_obs"][sl], fx["s0_actions"][:, sl], fx["s0_target_value"][:, sl],
                      fx["s0_target_reward"][:, sl], fx["s0_target_policy"][:, sl],
                      fx["s0_is_ratio"][sl].astype(np.float32), global_batch=B)
-grad = torch.from_numpy(out["grad"]); loss = torch.from_numpy(np.append(out["loss_terms"], np.float32(out["total_loss"])))
-assert train.allreduce_gradient(grad, loss) == world
+bucket, grad, loss = train.make_bucket(out["grad"].size, 5)
+grad.copy_(torch.from_numpy(out["grad"])); loss.copy_(torch.from_numpy(np.append(out["loss_terms"], np.float32(out["total_loss"]))))
+calls = []
+_ar = dist_all_reduce = torch.distributed.all_reduce
+torch.distributed.all_reduce = lambda *a, **k: (calls.append(1), _ar(*a, **k))[1]
+assert train.allreduce_gradient(bucket) == world
+torch.distributed.all_reduce = _ar
+assert len(calls) == 1, "a training step is ONE collective"
 blob = fx["blob0"].copy(); m = np.zeros_like(blob); v = np.zeros_like(blob)
 mzo.adam_step(blob, m, v, grad.numpy(), 1, train.scheduled_lr("cosineannealinglr", 0.01, 10000, 0))
 np.savez(os.environ["MZ_OUT"] + f".{rank}.npz", blob=blob, grad=grad.numpy(), loss=loss.numpy())

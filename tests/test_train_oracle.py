@@ -146,5 +146,28 @@ def test_scheduled_lr_closed_forms():
     assert scheduled_momentum("steplr", 50, 3) == 0.9
     with pytest.raises(ValueError):
         scheduled_lr("onecyclelr", 0.01, 5, 7)            # torch raises past total_steps
+    # the end of the cycle against torch itself, stepped the reference's way (optimizer.step(), then
+    # scheduler.step(epoch=count), muzero_model.py:764-786): train total_steps + 1 still runs, at the rate
+    # of one_cycle(total_steps), and only then torch raises
+    import warnings
+    import torch
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.Adam([p], lr=0.01)
+    sch = torch.optim.lr_scheduler.OneCycleLR(opt, max_lr=0.01, total_steps=10)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for count in range(12):
+            g = opt.param_groups[0]
+            assert abs(scheduled_lr("onecyclelr", 0.01, 10, count) - g["lr"]) < 1e-15
+            assert abs(scheduled_momentum("onecyclelr", 10, count) - g["betas"][0]) < 1e-15
+            p.grad = torch.ones(1)
+            opt.step()
+            if count < 11:
+                sch.step(epoch=count)
+            else:
+                with pytest.raises(ValueError):
+                    sch.step(epoch=count)
+    with pytest.raises(ValueError):
+        scheduled_lr("onecyclelr", 0.01, 10, 12)
     with pytest.raises(NotImplementedError):
         scheduled_lr("exponentiallr", 0.1, 10, 1)

@@ -104,3 +104,39 @@ def test_static_scratch_other_shape_and_unroll():
     for k in ("grad", "loss", "prio"):
         assert _same_bits(got[k], want[k]), k
     eng.close()
+
+
+def test_static_entry_point_allocates_no_device_memory():
+    """The property in the name: hipMemGetInfo's free bytes are the same before and after a run of
+    mzs_train_grad_static calls on a warmed handle with pre-allocated inputs and outputs (a later
+    hipMalloc on this path — a lazy buffer, say — would lower them)."""
+    import torch
+    from muzero_amd import _lib
+    from muzero_amd.engine import SearchEngine
+    fx = load_golden("train_tag123_K5_B128.npz")
+    K, B = int(fx["K"]), int(fx["B"])
+    inp = step_inputs(fx, 0)
+    eng = SearchEngine(tuple(int(x) for x in fx["dims"]), max_games=1, max_simulations=0)
+    eng.set_weights(fx["blob0"])
+    dev = eng.device
+    t = {k: (None if v is None else torch.as_tensor(np.ascontiguousarray(v, np.float32)).to(dev))
+         for k, v in inp.items()}
+    grad = torch.zeros(eng.weight_count(), dtype=torch.float32, device=dev)
+    loss = torch.zeros(3 * K, dtype=torch.float32, device=dev)
+    prio = torch.zeros((K, B), dtype=torch.float32, device=dev)
+    stream = eng._stream()
+
+    def call(n):
+        _lib.check(eng.lib.mzs_train_grad_static(eng.h, n, K, _p(t["obs"]), _p(t["actions"]), _p(t["target_value"]),
+                                                 _p(t["target_reward"]), _p(t["target_policy"]), _p(t["is_ratio"]),
+                                                 C.c_float(1.0 / n), _p(grad), _p(loss), _p(prio), stream), "static")
+
+    call(B)                                         # warm: code object load, first-call attribute queries
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info(dev)
+    for n in (B, 40, B, 7, B):
+        call(n)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info(dev)
+    assert free1 == free0, f"device memory changed by {free0 - free1} bytes across mzs_train_grad_static calls"
+    eng.close()

@@ -84,7 +84,7 @@ def main():
         if world > 1:
             t0 = time.perf_counter()
             for _ in range(n):
-                allreduce_gradient(tr.grad, tr.loss)
+                allreduce_gradient(tr.bucket)
             fence()
             ar_us = 1e6 * shard.max_over_ranks(time.perf_counter() - t0, dev) / n
         shard.assert_replicas_identical(tr.weights(), dev)          # replicas stayed bit-identical
@@ -93,7 +93,7 @@ def main():
                               "unroll": K, "batch_per_gpu": B,
                               "n_gpus": world, "global_batch": B * world, "ms_per_step": 1e3 * dt,
                               "samples_per_s": B * world / dt, "allreduce_us": ar_us,
-                              "bucket_floats": int(tr.grad.numel()),
+                              "bucket_floats": int(tr.bucket.numel()),
                               "note": "forward+losses+backward+wgrad, one all-reduce of the flat bucket, "
                                       "Adam; inputs resident"}), flush=True)
         eng.close()
