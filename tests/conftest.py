@@ -41,6 +41,15 @@ def fixture_streams(fx):
     return dirichlet, noise
 
 
+def fixture_obs(fx):
+    """Observations of a search fixture: stored, or — 'vision_model' fixtures, 115 KB per image —
+    regenerated from the seed tests/golden/make_vision_fixtures.py drew them from."""
+    if "obs" in fx:
+        return fx["obs"]
+    n = len(fx["seed"])
+    return np.random.RandomState(int(fx["obs_seed"])).uniform(0.0, 1.0, size=(n, 3, 98, 98)).astype(np.float32)
+
+
 SEARCH_FIXTURES = [
     ("search_tag123_S50.npz", "tag123"), ("search_tag123_S11.npz", "tag123"),
     ("search_tag123_S1.npz", "tag123"), ("search_tag123_S0.npz", "tag123"),
@@ -49,5 +58,7 @@ SEARCH_FIXTURES = [
     ("search_tag137_S25.npz", "tag137"), ("search_synA4_S50.npz", "synA4"),
     ("search_synA3_S30.npz", "synA3"),
     ("search_lstmA_S50.npz", "lstmA"), ("search_lstmB_S30.npz", "lstmB"),      # 'lstm_model'
+    ("search_visA_S30.npz", "visA"), ("search_visB_S20.npz", "visB"),          # 'vision_model'
+    ("search_visA_S12_notrain.npz", "visA"),
 ]
 MODEL_TAGS = ["tag123", "tag127", "tag133", "tag137", "synA4", "synA3", "lstmA", "lstmB"]

@@ -185,8 +185,12 @@ class RecordingMCTS(Monte_carlo_tree_search):
         return out
 
 
-def run_searches(mz, obs_batch, seeds, S, train, gamma, maxdepth_cap=None):
-    dims = model_dims(mz)
+def run_searches(mz, obs_batch, seeds, S, train, gamma, maxdepth_cap=None, dims=None, store_obs=True):
+    """dims: override of model_dims(mz) for models whose hidden state is not a vector of S_dim floats
+    (make_vision_fixtures.py: "hid_n" = floats of one hidden state); store_obs=False leaves the observations
+    out of the record (the caller stores the seed they are regenerated from)."""
+    dims = dict(model_dims(mz) if dims is None else dims)
+    hid_n = int(dims.pop("hid_n", dims["S_dim"]))
     A = dims["A"]
     N = len(seeds)
     rec = dict(
@@ -196,14 +200,14 @@ def run_searches(mz, obs_batch, seeds, S, train, gamma, maxdepth_cap=None):
         root_prior=np.zeros((N, A), np.float64),        # after noise (f64)
         root_policy=np.zeros((N, A), np.float32),       # network prior, before noise
         root_pred_value=np.zeros(N, np.float32),
-        root_hidden=np.zeros((N, dims["S_dim"]), np.float32),
+        root_hidden=np.zeros((N, hid_n), np.float32),
         dirichlet=np.zeros((N, A), np.float64), n_draws=np.zeros(N, np.int64),
         total_path_len=np.zeros(N, np.int64), min_margin=np.full(N, np.inf),
         max_depth=np.zeros(N, np.int32),
         sim_parent=np.zeros((N, S), np.int32), sim_action=np.zeros((N, S), np.int32),
         sim_reward=np.zeros((N, S), np.float32), sim_value=np.zeros((N, S), np.float32),
         sim_prior=np.zeros((N, S, A), np.float32),
-        sim_hidden=np.zeros((N, S, dims["S_dim"]), np.float32),
+        sim_hidden=np.zeros((N, S, hid_n), np.float32),
         child_visit=np.zeros((N, 1 + A * (S + 1)), np.int32),
         child_vsum=np.zeros((N, 1 + A * (S + 1)), np.float32),
         t0_action=np.zeros(N, np.int32),
@@ -234,7 +238,7 @@ def run_searches(mz, obs_batch, seeds, S, train, gamma, maxdepth_cap=None):
         rec["root_prior"][i] = [np.float64(root.children[a].prior) for a in range(A)]
         rec["root_policy"][i] = model.pred[0][0][0]
         rec["root_pred_value"][i] = model.pred[0][1]
-        rec["root_hidden"][i] = model.repr[0][0]
+        rec["root_hidden"][i] = model.repr[0][0].ravel()
         rec["total_path_len"][i] = sum(len(p) for p in mcts.paths)
         rec["max_depth"][i] = max([len(p) for p in mcts.paths] or [0])
         if mcts.margins:
@@ -253,7 +257,7 @@ def run_searches(mz, obs_batch, seeds, S, train, gamma, maxdepth_cap=None):
             a_, r_, h_ = model.dyn[s]
             assert a_ == leaf[-1]
             rec["sim_reward"][i, s] = r_
-            rec["sim_hidden"][i, s] = h_[0]
+            rec["sim_hidden"][i, s] = h_[0].ravel()
             rec["sim_prior"][i, s] = model.pred[s + 1][0][0]
             rec["sim_value"][i, s] = model.pred[s + 1][1]
         # final per-node statistics
@@ -279,6 +283,8 @@ def run_searches(mz, obs_batch, seeds, S, train, gamma, maxdepth_cap=None):
         pb_c = np.log((n + mcts.pb_c_base + 1) / mcts.pb_c_base) + mcts.pb_c_init
         tab[n] = np.sqrt(n) * pb_c
     rec["pbc_table"] = tab
+    if not store_obs:
+        del rec["obs"]
     return rec
 
 

@@ -130,6 +130,19 @@ def vision_vectors(mz, A, n, obs_seed, seed):
     return out
 
 
+def vision_searches(mz, A, Sd, H, L, n, obs_seed, seed0, S, train=True, gamma=0.997):
+    """The reference's Monte_carlo_tree_search.run (monte_carlo_tree_search.py:224-265) on the vision networks
+    through make_fixtures.RecordingMCTS: n searches of S simulations on seeded (1, 3, 98, 98) images, with the
+    per-simulation model outputs, consumed streams, final trees and decision margins of the MLP search
+    fixtures.  The images are regenerated from obs_seed by the tests (conftest.fixture_obs), not stored."""
+    obs = np.random.RandomState(obs_seed).uniform(0.0, 1.0, size=(n, 3, 98, 98)).astype(np.float32)
+    dims = dict(obs_dim=98, A=A, S_dim=Sd, H=H, L=L, hid_n=147)
+    rec = mf.run_searches(mz, obs, seed0 + np.arange(n), S, train, gamma, dims=dims, store_obs=False)
+    rec["obs_seed"] = np.int64(obs_seed)
+    rec["kind"] = np.int64(2)
+    return rec
+
+
 def main():
     torch.set_num_threads(1)
     for name, (A, Sd, H, L, seed) in {"visA": (2, 31, 64, 1, 41), "visB": (4, 21, 32, 2, 42)}.items():
@@ -147,6 +160,12 @@ def main():
         mf.save(f"weights_{name}.npz", blob=blob, kind=np.int64(2), obs_dim=np.int64(98), A=np.int64(A),
                 S_dim=np.int64(Sd), H=np.int64(H), L=np.int64(L))
         mf.save(f"model_L2_{name}.npz", **vision_vectors(mz, A, 12, 900 + seed, 31 + seed))
+        S = 30 if name == "visA" else 20
+        mf.save(f"search_{name}_S{S}.npz", **vision_searches(mz, A, Sd, H, L, 16, 1900 + seed, 15000 + 100 * seed, S))
+    mz = vision_model(2, 31, 64, 1, 41)
+    for net in (mz.representation_function, mz.dynamics_function, mz.prediction_function):
+        net.eval()
+    mf.save("search_visA_S12_notrain.npz", **vision_searches(mz, 2, 31, 64, 1, 8, 1990, 16000, 12, train=False))
 
 
 if __name__ == "__main__":

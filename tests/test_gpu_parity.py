@@ -10,7 +10,7 @@ inverse transform, see tests/test_oracle_golden.py::value_err).
 import numpy as np
 import pytest
 
-from conftest import (MODEL_TAGS, SEARCH_FIXTURES, fixture_streams, fixture_weights, load_golden)
+from conftest import (MODEL_TAGS, SEARCH_FIXTURES, fixture_obs, fixture_streams, fixture_weights, load_golden)
 from test_oracle_golden import (REL, check_L3_against_reference, hidden_err, leaves_of, rel_err, table_of,
                                 value_err)
 
@@ -110,11 +110,11 @@ def test_L3_search_end_to_end(fname, tag, engine):
     train = bool(fx["train"])
     eng = make_engine(d, G, S, float(fx["gamma"]), float(fx["frac"]), engine)
     eng.set_weights(blob)
-    eng.search(fx["obs"], dirichlet if train and S > 0 else None, noise if S > 0 else None, S, train)
+    eng.search(fixture_obs(fx), dirichlet if train and S > 0 else None, noise if S > 0 else None, S, train)
     out = eng.results_host()
     tree = eng.tree_host()
     ref = mzo.search(d, blob, S, float(fx["gamma"]), float(fx["frac"]), fx["pbc_table"],
-                     obs=fx["obs"], dirichlet=dirichlet, noise=noise, train=train,
+                     obs=fixture_obs(fx), dirichlet=dirichlet, noise=noise, train=train,
                      want=("visits", "root_value", "root_prior", "consumed", "path_len", "sim_leaf",
                            "node_visit", "node_vsum", "node_reward", "node_prior", "child_base",
                            "minmax", "hidden"))
