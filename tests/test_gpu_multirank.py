@@ -82,3 +82,15 @@ def test_bench_two_ranks_reports_two_gpus():
     j = json.loads(line)
     assert j["n_gpus"] == 2 and j["config"]["world_size"] == 2 and j["config"]["backend"] == "nccl"
     assert j["scaling"] == "weak" and j["value"] > 0
+
+
+def test_selfplay_bench_two_ranks():
+    """tools/bench_selfplay.py --gpus 2: an arena + replay store per rank (disjoint game seeds), data-parallel
+    training steps through ONE all-reduce each; the run itself asserts the replicas' weights stayed identical."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_selfplay.py"), "--gpus", "2", "--games", "256",
+                        "--sims", "10", "--max-moves", "40", "--rounds", "2", "--games-per-round", "512", "--train-steps",
+                        "4", "--batch", "64", "--rolling"], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    j = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert j["n_gpus"] == 2 and j["global_batch"] == 128 and j["games_per_round_whole_job"] == 1024
+    assert j["useful_sims_per_s"] > 0 and 0.3 < j["slot_utilisation"] <= 1.0

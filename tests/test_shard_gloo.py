@@ -162,6 +162,69 @@ def test_self_play_shards_by_game_seed(tmp_path):
     assert int(got["big_n"]) == int(ar.length[:40].sum())
 
 
+LOOP_WORKER = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["MZ_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MZ_ROOT"], "tests"))
+from muzero_amd import shard, selfplay, train
+from oracle import mz_oracle as mzo
+from conftest import fixture_weights
+import torch.distributed as dist
+rank, world = shard.init("gloo")
+d, blob = fixture_weights("tag123")
+blob = blob.copy(); m = np.zeros_like(blob); v = np.zeros_like(blob)
+N, G, T, B, K, td = 24, 8, 20, 16, 3, 5
+dp = selfplay.discount_powers(0.997, td)
+store = selfplay.ReplayStore(4 * N, B, K, td, discount=0.997)
+np.random.seed(100 + rank)
+calls = []
+_ar = torch.distributed.all_reduce
+torch.distributed.all_reduce = lambda *a, **k: (calls.append(1), _ar(*a, **k))[1]
+ar = mzo.ArenaOracle(G, T, n_rows=4 * N)
+for it in range(2):                                   # learning_cycle: play a round, then train (self_play.py:217-262)
+    seeds = (selfplay.game_seed_index(rank, N) * 2654435761 + 5) & 0x7FFFFFFF
+    rows = np.arange(it * N, (it + 1) * N)
+    ar.begin(seeds, episode=it, row0=it * N)
+    while True:                  # stand-in search results from the observation + the CURRENT weights (rank-identical)
+        bias = float(blob[:8].sum())
+        vis = np.stack([(ar.obs[:, 2] + bias > 0) * 30 + 10, (ar.obs[:, 2] + bias <= 0) * 30 + 10], 1).astype(np.int32)
+        if ar.step(vis, ar.obs[:, 0], np.full((G, 2), 0.5), 1.0) == 0:
+            break
+    prio = mzo.make_priority(ar.length[rows], ar.traj_reward[rows], ar.traj_root[rows], td, dp)
+    store.save_games(rows, ar.length[rows], priorities=prio)
+    for step in range(3):
+        row_pos, ratio, game_pos = store.sample_batch()
+        obs, actions, tv, tr, tp = mzo.make_batch(ar.length, ar.traj_obs, ar.traj_action, ar.traj_reward, ar.traj_root,
+                                                  ar.traj_policy, row_pos, K, td, dp)
+        out = mzo.train_grad(d, blob, obs, actions, tv, tr, tp, np.asarray(ratio, np.float32), global_batch=B * world)
+        bucket, grad, loss = train.make_bucket(out["grad"].size, K)
+        grad.copy_(torch.from_numpy(out["grad"]))
+        loss.copy_(torch.from_numpy(np.append(out["loss_terms"], np.float32(out["total_loss"]))))
+        train.allreduce_gradient(bucket)
+        mzo.adam_step(blob, m, v, grad.numpy(), 3 * it + step + 1, 0.01)
+        store.update_value(out["priority"], game_pos)
+assert len(calls) == 6, calls                          # ONE collective per training step, none in the play path
+torch.distributed.all_reduce = _ar
+shard.assert_replicas_identical(blob)
+np.savez(os.environ["MZ_OUT"] + f".{rank}.npz", blob=blob, lengths=ar.length, loss=loss.numpy())
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_self_play_training_loop_two_ranks(tmp_path):
+    """The multi-rank learning cycle on CPU stand-ins (oracle arena, oracle training step): every rank plays its
+    own games and samples its own replay store, a training step is ONE all-reduce of the gradient bucket, and
+    the replicas' weights — which steer the next round's play — stay bit-identical.  The GPU counterpart is
+    tools/bench_selfplay.py --gpus N (tests/test_gpu_multirank.py)."""
+    out = str(tmp_path / "loop")
+    run_two_ranks(tmp_path, "loop_worker.py", LOOP_WORKER, out)
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    assert np.array_equal(r0["blob"], r1["blob"]) and np.array_equal(r0["loss"], r1["loss"])
+    assert not np.array_equal(r0["lengths"], r1["lengths"])          # different games on the two ranks
+    d, blob = fixture_weights("tag123")
+    assert np.abs(r0["blob"] - blob).max() > 1e-3 and np.isfinite(r0["loss"]).all()
+
+
 BCAST_WORKER = r'''
 import os, sys
 import numpy as np, torch

@@ -1,7 +1,14 @@
 #!/usr/bin/env python3
 """Throughput of the batched self-play loop on one MI355X: G games x S simulations per move,
 fill_streams -> search -> arena step per move, then sample / gather / train steps.
-Prints one JSON line.  Usage: python tools/bench_selfplay.py [--games 4096] [--sims 50]"""
+Prints one JSON line.  Usage: python tools/bench_selfplay.py [--games 4096] [--sims 50] [--gpus N]
+
+--gpus N > 1 starts N ranks itself (muzero_amd.shard.launch_ranks: one process per GPU, RCCL): every rank
+owns an arena and a replay store and plays its own games (seeds offset by rank, no collective in the play
+path, as self_play.py:212-236 hands whole games to Ray workers); the training steps are data-parallel —
+one all_reduce of the gradient bucket per step (muzero_amd.train) — so the replicas' weights stay
+identical, which the run asserts at the end.  Rank 0 prints the whole job's figures: game moves and
+simulations summed over the ranks, divided by the slowest rank's time."""
 import argparse
 import json
 import os
@@ -12,9 +19,6 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from muzero_amd.engine import SearchEngine  # noqa: E402
-from muzero_amd.selfplay import Arena, ReplayStore, SelfPlay, play_round  # noqa: E402
-from muzero_amd.train import Trainer  # noqa: E402
 
 
 def main():
@@ -29,10 +33,28 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"), help="precision of the model half of the search")
     ap.add_argument("--rolling", action="store_true",
                     help="queue the next round's games while the current one drains (SelfPlay(rolling=True))")
+    ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU); > 1 starts them itself")
+    ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
     a = ap.parse_args()
+
+    from muzero_amd import shard
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(shard.launch_ranks(os.path.abspath(__file__), sys.argv[1:], a.gpus))
+    if shard.rank_world()[1] != a.gpus:
+        sys.exit(f"bench_selfplay.py: --gpus {a.gpus} but WORLD_SIZE={shard.rank_world()[1]}")
+    if shard.visible_gpus() < a.gpus:
+        sys.exit(f"bench_selfplay.py: --gpus {a.gpus} but only {shard.visible_gpus()} GPU(s) are visible")
+    import torch.distributed as dist
+    from muzero_amd.engine import SearchEngine
+    from muzero_amd.selfplay import Arena, ReplayStore, SelfPlay, play_round
+    from muzero_amd.train import Trainer
+    rank, world = shard.init(a.backend)
+    local = int(os.environ.get("LOCAL_RANK", "0")) if world > 1 else 0
+    torch.cuda.set_device(local)
+
     G, S, T = a.games, a.sims, a.max_moves
     dims = (4, 2, 31, 64, 0, 0, 1 if a.dtype == "bf16" else 0)
-    eng = SearchEngine(dims, max_games=G, max_simulations=S, discount=0.997)
+    eng = SearchEngine(dims, max_games=G, max_simulations=S, discount=0.997, device=local)
     n = eng.weight_count()
     w0 = (np.random.RandomState(0).standard_normal(n) * 0.1).astype(np.float32)
     eng.set_weights(w0)
@@ -44,13 +66,13 @@ def main():
         eng.set_weights(w0)        # both passes play the same games (the optimizer state carries over, harmless)
         store = ReplayStore(window_size=N, batch_size=a.batch, num_unroll=K, td_steps=td, discount=0.997)
         ar = Arena(eng, G, (4 if a.rolling else 3) * N, T)
-        loop = SelfPlay(None, eng, tr, ar, store, S, games_per_iteration=N, seed=1, rolling=a.rolling)
-        np.random.seed(0)
+        loop = SelfPlay(None, eng, tr, ar, store, S, games_per_iteration=N, seed=1, rolling=a.rolling, rank=rank)
+        np.random.seed(rank)
         out = []
         for r in range(a.rounds):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            if r == a.rounds - 1 and not a.rolling:          # last round: time the device loop alone
+            if r == a.rounds - 1 and not a.rolling and world == 1:   # last round: time the device loop alone
                 seeds = (np.arange(N, dtype=np.int64) * 2654435761 + 99) & 0x7FFFFFFF
                 mv = play_round(eng, ar, seeds, 1000 + r, S, 1.0, loop.block * N)
                 torch.cuda.synchronize()
@@ -76,6 +98,8 @@ def main():
         return out
 
     run_once()            # warm-up pass: module load, kernel attribute calls, allocator growth
+    if world > 1:
+        dist.barrier()
     out = run_once()
     # Totals over ALL rounds of the measured pass.  With rolling rounds a round's lock-step moves also
     # advance the next round's early games, so only the totals mean something: game moves recorded /
@@ -84,12 +108,29 @@ def main():
     tot_moves = sum(o["game_moves"] for o in rr)
     tot_lock = sum(o["lockstep_moves"] for o in rr)
     tot_play = sum(o["play_s"] for o in rr)
-    print(json.dumps(dict(games_per_round=N, slots=G, sims=S, max_moves=T, batch=a.batch, rolling=a.rolling, dtype=a.dtype,
-                          kernel=eng.search_kernel_name(S),
-                          rounds_timed=len(rr), slot_utilisation=tot_moves / (tot_lock * G),
-                          useful_sims_per_s=tot_moves * S / tot_play,
-                          search_sims_per_s=tot_lock * G * S / tot_play,
-                          ms_per_lockstep_move=tot_play * 1e3 / tot_lock, rounds=out)))
+    tot_train = sum(o["train_ms_per_step"] for o in rr) * a.train_steps * 1e-3
+    job_moves, job_lock = tot_moves, tot_lock
+    if world > 1:
+        # whole-job figures: work summed over the ranks, time of the slowest rank (the ranks meet in every
+        # training step's all-reduce, so their rounds stay in step)
+        t = torch.tensor([tot_moves, tot_lock], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        job_moves, job_lock = int(t[0].item()), int(t[1].item())
+        tot_play = shard.max_over_ranks(tot_play, eng.device)
+        tot_train = shard.max_over_ranks(tot_train, eng.device)
+        shard.assert_replicas_identical(tr.weights(), eng.device)      # the data-parallel steps kept them equal
+    if rank == 0:
+        print(json.dumps(dict(n_gpus=world, games_per_round=N, games_per_round_whole_job=N * world, slots=G, sims=S,
+                              max_moves=T, batch=a.batch, global_batch=a.batch * world, rolling=a.rolling,
+                              dtype=a.dtype, kernel=eng.search_kernel_name(S),
+                              rounds_timed=len(rr), slot_utilisation=job_moves / (job_lock * G),
+                              useful_sims_per_s=job_moves * S / tot_play,
+                              search_sims_per_s=job_lock * G * S / tot_play,
+                              ms_per_lockstep_move=tot_play * 1e3 / tot_lock,
+                              train_ms_per_step=tot_train * 1e3 / (a.train_steps * len(rr)), rounds=out)), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
