@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/mzsearch.h"
+#include "../../include/mzs_crmath.h"
 #include "mzs_device.h"
 #include "mzs_quad.h"
 #include "mzs_search_kernels.h"
@@ -542,7 +543,10 @@ __global__ void __launch_bounds__(256) k_inference(const InferParams p) {
  * dirichlet([alpha] * A) followed by uniform(lo, hi, size = n) — the numbers the reference
  * draws from NumPy's global legacy stream after np.random.seed(seed)
  * (monte_carlo_tree_search.py:140, :163).  MT19937 (init_genrand seeding, 53-bit doubles from
- * two tempered words), legacy standard_gamma for shape <= 1.
+ * two tempered words), legacy standard_gamma for shape <= 1, its log and pow from include/mzs_crmath.h
+ * (double-double, rounded once: the correctly rounded double, which is what glibc's libm under NumPy
+ * returns in all but ~0.07 % of the calls — oracle/mz_stream_oracle.c is this sampler on the CPU, equal
+ * to the device bit for bit and pinned to NumPy by tests/test_crmath.py).
  * One workgroup = sixteen games.  init_genrand is a serial chain of 624 multiply-xorshift steps per
  * game, so the sixteen chains run side by side in sixteen lanes of wave 0 (states in LDS); then one
  * wavefront per game: the 624-word state refresh, the gamma draws and the uniform fill are spread
@@ -616,17 +620,17 @@ struct MtStream {
 
 /* legacy_standard_gamma, shape <= 1 (numpy/random/src/legacy/legacy-distributions.c) */
 __device__ __forceinline__ double mt_standard_gamma(MtStream& r, double shape) {
-    if (shape == 1.0) return -log(1.0 - r.next_double());
+    if (shape == 1.0) return -mzs_cr_log(1.0 - r.next_double());
     if (shape == 0.0) return 0.0;
     for (;;) {
         const double U = r.next_double();
-        const double V = -log(1.0 - r.next_double());
+        const double V = -mzs_cr_log(1.0 - r.next_double());
         if (U <= 1.0 - shape) {
-            const double X = pow(U, 1.0 / shape);
+            const double X = mzs_cr_pow(U, 1.0 / shape);
             if (X <= V) return X;
         } else {
-            const double Y = -log((1.0 - U) / shape);
-            const double X = pow(1.0 - shape + shape * Y, 1.0 / shape);
+            const double Y = -mzs_cr_log((1.0 - U) / shape);
+            const double X = mzs_cr_pow(1.0 - shape + shape * Y, 1.0 / shape);
             if (X <= V + Y) return X;
         }
     }
@@ -637,10 +641,10 @@ __device__ __forceinline__ double mt_standard_gamma(MtStream& r, double shape) {
  * two doubles, so attempt number m of a stream reads words [4m, 4m + 4) whatever happened before. */
 __device__ __forceinline__ bool mt_gamma_attempt(double U, double Vd, double shape, double* X) {
     /* both arms of the sampler end in pow(., 1 / shape): select the base, call pow once */
-    const double V = -log(1.0 - Vd);
+    const double V = -mzs_cr_log(1.0 - Vd);
     const bool low = U <= 1.0 - shape;
-    const double Y = low ? 0.0 : -log((1.0 - U) / shape);
-    *X = pow(low ? U : 1.0 - shape + shape * Y, 1.0 / shape);
+    const double Y = low ? 0.0 : -mzs_cr_log((1.0 - U) / shape);
+    *X = mzs_cr_pow(low ? U : 1.0 - shape + shape * Y, 1.0 / shape);
     return *X <= V + Y; /* low arm: X <= V */
 }
 

@@ -67,6 +67,11 @@ def lib():
         _LIB.mzo_expf.argtypes = [C.c_float]
         _LIB.mzo_elu.restype = C.c_float
         _LIB.mzo_elu.argtypes = [C.c_float]
+        _LIB.mzo_cr_log.restype = C.c_double
+        _LIB.mzo_cr_log.argtypes = [C.c_double]
+        _LIB.mzo_cr_pow.restype = C.c_double
+        _LIB.mzo_cr_pow.argtypes = [C.c_double, C.c_double]
+        _LIB.mzo_stream.restype = C.c_int
     return _LIB
 
 
@@ -97,6 +102,23 @@ def round_bf16(x):
 
 def _f32(a):
     return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def streams(seeds, n_actions, num_simulations, alpha=0.25, train=True, lo=1e-7, hi=2e-7, n_uniform=None):
+    """mz_stream_oracle.c: RandomState(seed).dirichlet([alpha] * A) then .uniform(lo, hi, n) per seed, with
+    log / pow from include/mzs_crmath.h: (dirichlet [G, A] or zeros, noise [G, n])."""
+    seeds = np.ascontiguousarray(seeds, np.int64).ravel()
+    A, S = int(n_actions), int(num_simulations)
+    n = A * S * (S + 1) // 2 if n_uniform is None else int(n_uniform)
+    d = np.zeros((len(seeds), A), np.float64)
+    u = np.zeros((len(seeds), max(n, 1)), np.float64)
+    tr = int(bool(train) and S > 0)
+    for g, seed in enumerate(seeds):
+        rc = lib().mzo_stream(C.c_int64(int(seed)), C.c_int(A), C.c_double(alpha), C.c_int(tr), C.c_double(lo),
+                              C.c_double(hi), C.c_int64(n), _p(d[g]), _p(u[g]))
+        if rc != 0:
+            raise ValueError("mzo_stream: alpha must be <= 1")
+    return d, u
 
 
 VISION_HIDDEN = 3 * 7 * 7
