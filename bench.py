@@ -91,7 +91,7 @@ def main():
     ap.add_argument("--games", type=int, default=4096, help="games per GPU")
     ap.add_argument("--sims", type=int, default=50)
     ap.add_argument("--weights", default="tag123")
-    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"),
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16", "bf16x3"),
                     help="f32: the bit-exact headline; bf16: the 1e-2 variant (weights / layer inputs in bfloat16, "
                          "v_mfma_f32_4x4x4_16B_bf16), its own roofline against the bf16 matrix peak")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -122,7 +122,7 @@ def main():
 
     w = np.load(os.path.join(ROOT, "tests", "golden", f"weights_{args.weights}.npz"))
     kind = int(w["kind"]) if "kind" in w.files else 0
-    dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (kind, 1 if args.dtype == "bf16" else 0)
+    dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (kind, {"f32": 0, "bf16": 1, "bf16x3": 2}[args.dtype])
     obs_dim, A, S_dim, H, L = dims[:5]
     model_name = "LSTM" if kind == 1 else "MLP"
     G, S = args.games, args.sims
@@ -232,8 +232,8 @@ def main():
                 traffic = tj["hbm_bytes_per_launch"]
         except (OSError, ValueError, KeyError):
             pass
-        peak = BF16_MATRIX_PEAK_TFLOPS if args.dtype == "bf16" else F32_MATRIX_PEAK_TFLOPS
-        if args.dtype == "bf16":
+        peak = BF16_MATRIX_PEAK_TFLOPS if args.dtype != "f32" else F32_MATRIX_PEAK_TFLOPS
+        if args.dtype != "f32":
             traffic = None      # profiles/traffic.json is the fp32 kernel's
         out["roofline"] = {"bound": "mfma", "achieved": fl, "peak": peak,
                            "unit": "TFLOP/s", "frac": fl / peak, "traffic": traffic,

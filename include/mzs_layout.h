@@ -45,13 +45,16 @@ typedef struct mzs_dims {
                              num_layers of every nn.LSTM (LSTM model, 1..MZS_LSTM_MAX_LAYERS) */
     int32_t model_kind;   /* MZS_MODEL_MLP (0, 'mlp_model'), MZS_MODEL_LSTM ('lstm_model') or
                              MZS_MODEL_VISION ('vision_model', inference entry points only)     */
-    int32_t precision;    /* MZS_PRECISION_F32 (0) or MZS_PRECISION_BF16: Muzero(type_format=...),
-                             muzero_model.py:194-204.  bf16 = weights and layer inputs rounded to
-                             bfloat16, fp32 accumulation and epilogues (include/mzs_numeric.h)   */
+    int32_t precision;    /* MZS_PRECISION_F32 (0), MZS_PRECISION_BF16 or MZS_PRECISION_BF16X3:
+                             Muzero(type_format=...), muzero_model.py:194-204.  bf16 = weights and layer
+                             inputs rounded to bfloat16, fp32 accumulation and epilogues; bf16x3 = both
+                             kept as a hi + lo PAIR of bfloat16s, three matrix products per layer
+                             (include/mzs_numeric.h "dot_bf16" / "dot_bf16x3")                    */
 } mzs_dims;
 
 #define MZS_PRECISION_F32 0
-#define MZS_PRECISION_BF16 1
+#define MZS_PRECISION_BF16 1   /* fast: within 1e-2 of the reference on the CartPole checkpoints 123 / 133 */
+#define MZS_PRECISION_BF16X3 2 /* compensated: within 1e-2 (measured 2e-3) on every fixture weight set   */
 
 #define MZS_MODEL_MLP 0
 #define MZS_MODEL_LSTM 1

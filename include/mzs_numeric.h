@@ -231,6 +231,28 @@ MZS_FN float mzs_dot4_bf16(const unsigned short* a, const unsigned short* b) {
     return (r * mzs_pow2i(h)) * mzs_pow2i(sc - h);
 }
 
+/* ---------------------------------------------------------------------------------------------
+ * bf16x3 (MZS_PRECISION_BF16X3): the bf16 matrix instruction with nothing rounded away that matters.
+ * One bfloat16 keeps 8 significand bits; rounding the WEIGHTS alone to it already moves a value of the
+ * synthetic A = 3 / A = 4 fixture models by 18-20 % of north_star's 1e-2 x 100 (tools/bf16_scheme_study.py:
+ * weights bf16 + inputs exact: 0.2; inputs as a hi + lo pair does not help).  So both operands are split
+ *     v = v_h + v_l,   v_h = bf16(v),   v_l = bf16(v - v_h)      (v - v_h is exact in fp32)
+ * and a layer is three products, the lo x lo one (2^-18 relative) dropped:
+ *
+ *   dot_bf16x3 : k zero-padded to a multiple of 4; for every group i of four consecutive k
+ *                  a_i = mzs_dot4_bf16(w_h, x_h)   b_i = mzs_dot4_bf16(w_h, x_l)   c_i = mzs_dot4_bf16(w_l, x_h)
+ *                four chains of IEEE fp32 additions, each left to right:
+ *                  e = bias + a_0 + a_2 + ...      o = a_1 + a_3 + ...  (starts AT a_1)
+ *                  s = b_0 + b_1 + b_2 + ...       t = c_0 + c_1 + c_2 + ...
+ *                  y = (e + o) + (s + t)
+ * Weights used outside a dot (the one-hot action column) stay fp32.  Same instruction, same zero
+ * accumulator, same pinned mzs_dot4_bf16 as "dot_bf16".
+ * ------------------------------------------------------------------------------------------- */
+MZS_FN void mzs_bf16_split(float v, unsigned short* hi, unsigned short* lo) {
+    *hi = mzs_f2bf16(v);
+    *lo = mzs_f2bf16(v - mzs_bf16_2f(*hi));
+}
+
 /* next power of two >= n (n >= 1) */
 MZS_FN int mzs_pow2_ceil(int n) {
     int p = 1;

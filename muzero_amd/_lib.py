@@ -38,7 +38,7 @@ ARENA_LENGTH, ARENA_OBS, ARENA_ACTION, ARENA_REWARD, ARENA_ROOT_VALUE, ARENA_POL
 ARENA_ALIVE, ARENA_STATE, ARENA_STREAM_SEED, ARENA_SLOT_ROW, ARENA_QUEUE = 6, 7, 8, 9, 10
 ENV_CARTPOLE = 0
 MODEL_MLP, MODEL_LSTM, MODEL_VISION = 0, 1, 2
-PRECISION_F32, PRECISION_BF16 = 0, 1
+PRECISION_F32, PRECISION_BF16, PRECISION_BF16X3 = 0, 1, 2
 
 
 class Config(C.Structure):

@@ -51,7 +51,8 @@ struct LstmHead {
 struct Model {
     int obs_dim, A, Sd, H, L;
     int kind;       /* MZS_MODEL_MLP / MZS_MODEL_LSTM / MZS_MODEL_VISION (include/mzs_layout.h) */
-    int bf16;       /* 1: contract "dot_bf16" (include/mzs_numeric.h); w then holds bf16-rounded weights */
+    int bf16;       /* the handle's precision: MZS_PRECISION_BF16 = contract "dot_bf16" (w then holds bf16-rounded
+                       weights), MZS_PRECISION_BF16X3 = "dot_bf16x3" (w = the fp32 store, split on use) */
     int seg_state;  /* offset of the next-state segment in the dynamics heads (reward at 0) */
     int seg_value;  /* offset of the value segment in the prediction heads (policy at 0)     */
     Layer r_in, r_mid, r_out, d_in, d_mid, d_heads, p_in, p_mid, p_heads;
@@ -209,9 +210,48 @@ __device__ __forceinline__ void wave_dense_bf16(const float* __restrict__ w, con
     wave_sync();
 }
 
+/* contract "dot_bf16x3" without the matrix core: weights (from the fp32 store) and inputs split into hi + lo
+ * bfloat16 pairs, three mzs_dot4_bf16 per group, four chains (include/mzs_numeric.h) */
+template <bool kElu>
+__device__ __forceinline__ void wave_dense_bf16x3(const float* __restrict__ w, const Layer ly, const float* x,
+                                                  float* out, int extra_row, int lane) {
+    const int ng = (ly.k + 3) / 4;
+    for (int j0 = 0; j0 < ly.n_pad; j0 += kWave) {
+        const int j = j0 + lane;
+        const float* __restrict__ wt = w + ly.w_off + j;
+        float e = w[ly.b_off + j], o = 0.0f, s = 0.0f, t = 0.0f;
+        for (int g = 0; g < ng; ++g) {
+            unsigned short wh[4], wl[4], xh[4], xl[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int k = 4 * g + q;
+                const bool in = k < ly.k;
+                mzs_bf16_split(in ? wt[(size_t)k * ly.n_pad] : 0.0f, &wh[q], &wl[q]);
+                mzs_bf16_split(in ? x[k] : 0.0f, &xh[q], &xl[q]);
+            }
+            const float a = mzs_dot4_bf16(wh, xh), b = mzs_dot4_bf16(wh, xl), c = mzs_dot4_bf16(wl, xh);
+            if (g & 1)
+                o = g == 1 ? a : o + a;
+            else
+                e = e + a;
+            s = g == 0 ? b : s + b;
+            t = g == 0 ? c : t + c;
+        }
+        float acc = (e + o) + (s + t);
+        if (extra_row >= 0) acc = acc + wt[(size_t)extra_row * ly.n_pad];
+        if (kElu) acc = mzs_elu(acc);
+        out[j] = acc;
+    }
+    wave_sync();
+}
+
 template <bool kElu>
 __device__ __forceinline__ void wave_dense(const float* __restrict__ w, const Layer ly,
                                            const float* x, float* out, int extra_row, int lane, int bf16 = 0) {
+    if (bf16 == MZS_PRECISION_BF16X3) {
+        wave_dense_bf16x3<kElu>(w, ly, x, out, extra_row, lane);
+        return;
+    }
     if (bf16) {
         wave_dense_bf16<kElu>(w, ly, x, out, extra_row, lane);
         return;

@@ -269,7 +269,8 @@ __device__ __forceinline__ void quad_write_out(const SearchParams& p, const Quad
 /* kOcc: wavefronts per SIMD the register budget is compiled for.  2 (bf16 + kHidG only: packed weights
  * take half the registers and the trees of sixteen games 50 KB of LDS) lets two blocks share a CU when
  * a batch has more than sixteen games per CU: each wave's dependent chains hide behind the other's. */
-template <int SD, int NA, int H, bool kInjected, bool kMid = false, bool kHidG = false, bool kB16 = false, int kOcc = 1>
+/* kB16 == 2: contract "dot_bf16x3" (hi + lo pairs, three MFMAs per group; MZS_PRECISION_BF16X3) */
+template <int SD, int NA, int H, bool kInjected, bool kMid = false, bool kHidG = false, int kB16 = 0, int kOcc = 1>
 __global__ void __launch_bounds__(256, kOcc) k_search_quad(const SearchParams p, const QuadLayout ql) {
     extern __shared__ __align__(16) unsigned char smem[];
     const QuadLane q = quad_lane();
@@ -280,12 +281,16 @@ __global__ void __launch_bounds__(256, kOcc) k_search_quad(const SearchParams p,
     if (redo_skip_block(p, 4 * (blockDim.x >> 6))) return;
     /* block-shared tables, register-resident weights, then the only other block-level barrier */
     quad_fill_tables(smem, ql, p);
-    typename std::conditional<kB16, QuadWeightsB<SD, NA, H, kMid>, QuadWeights<SD, NA, H, kMid>>::type W;
+    typename std::conditional<kB16 == 2, QuadWeightsX3<SD, NA, H, kMid>,
+                              typename std::conditional<kB16 == 1, QuadWeightsB<SD, NA, H, kMid>,
+                                                        QuadWeights<SD, NA, H, kMid>>::type>::type W;
     if (!kInjected) {
         float* onehot_s = reinterpret_cast<float*>(smem + ql.off_onehot);
         for (int i = threadIdx.x; i < NA * 64; i += blockDim.x)
             onehot_s[i] = m.w[m.d_in.w_off + (SD + (i >> 6)) * 64 + (i & 63)];
-        if constexpr (kB16)
+        if constexpr (kB16 == 2)
+            quad_load_weights_x3<SD, NA, H, kMid>(m, W, q);
+        else if constexpr (kB16 == 1)
             quad_load_weights_b<SD, NA, H, kMid>(m, W, q);
         else
             quad_load_weights<SD, NA, H, kMid>(m, W, q);
@@ -322,14 +327,18 @@ __global__ void __launch_bounds__(256, kOcc) k_search_quad(const SearchParams p,
             for (int k = q.b; k < m.obs_dim; k += 16) L.trunk[q.c * kTrunkStride + k] = p.obs[(size_t)g * m.obs_dim + k];
         }
         wave_sync();
-        if constexpr (kB16)
+        if constexpr (kB16 == 2)
+            quad_representation_x3<SD, NA, H>(m, L, q, L.hid);
+        else if constexpr (kB16 == 1)
             quad_representation_b<SD, NA, H>(m, L, q, L.hid);
         else
             quad_representation<SD, NA, H>(m, L, q, L.hid);
         if constexpr (kHidG) {
             if (q.b < 8) *reinterpret_cast<float4*>(hid_g + 4 * q.b) = *reinterpret_cast<const float4*>(L.hid + 4 * q.b);
         }
-        if constexpr (kB16)
+        if constexpr (kB16 == 2)
+            (void)quad_prediction_x3<SD, NA, H, kMid>(W, L, q, L.hid, &pr, m.L);
+        else if constexpr (kB16 == 1)
             (void)quad_prediction_b<SD, NA, H, kMid>(W, L, q, L.hid, &pr, m.L);
         else
             (void)quad_prediction<SD, NA, H, kMid>(W, L, q, L.hid, &pr, m.L);   /* the root's value is not used */
@@ -365,7 +374,9 @@ __global__ void __launch_bounds__(256, kOcc) k_search_quad(const SearchParams p,
                 wave_sync();
             }
             float yr;
-            if constexpr (kB16)
+            if constexpr (kB16 == 2)
+                yr = quad_dynamics_x3<SD, NA, H, kMid>(W, L, q, hp, sel.action, hn, m.L);
+            else if constexpr (kB16 == 1)
                 yr = quad_dynamics_b<SD, NA, H, kMid>(W, L, q, hp, sel.action, hn, m.L);
             else
                 yr = quad_dynamics<SD, NA, H, kMid>(W, L, q, hp, sel.action, hn, m.L);
@@ -377,7 +388,9 @@ __global__ void __launch_bounds__(256, kOcc) k_search_quad(const SearchParams p,
             DIAG_T(t2);
             DIAG_ADD(2, t1, t2);
             float yv;
-            if constexpr (kB16)
+            if constexpr (kB16 == 2)
+                yv = quad_prediction_x3<SD, NA, H, kMid>(W, L, q, hn, &pr, m.L);
+            else if constexpr (kB16 == 1)
                 yv = quad_prediction_b<SD, NA, H, kMid>(W, L, q, hn, &pr, m.L);
             else
                 yv = quad_prediction<SD, NA, H, kMid>(W, L, q, hn, &pr, m.L);

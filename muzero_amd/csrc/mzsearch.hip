@@ -878,7 +878,7 @@ void describe_model(const mzs_dims& d, Model* m, StoreBuilder* sb) {
     m->H = H;
     m->L = d.n_mid_layers;
     m->kind = d.model_kind;
-    m->bf16 = d.precision == MZS_PRECISION_BF16;
+    m->bf16 = d.precision; /* 0, MZS_PRECISION_BF16 or MZS_PRECISION_BF16X3 */
     m->seg_state = round_up(Sd, 32);
     m->seg_value = Sd > 32 ? 64 : round_up(A, 32); /* wide heads: one 64-neuron group each (mzs_quadw.h) */
     m->hid = mzs_hidden_floats(&d);
@@ -1050,18 +1050,18 @@ quad_kernel_t pick_quad_kernel_t(const mzs_dims& d) {
 }
 /* hid_global: the variant that keeps the expansions' hidden states in the global SoA array */
 quad_kernel_t pick_quad_kernel(const mzs_dims& d, bool hid_global = false) {
-    if (d.precision == MZS_PRECISION_BF16) return mzs::pick_quad_kernel_bf16(d, hid_global); /* mzsearch_bf16.hip */
+    if (d.precision != MZS_PRECISION_F32) return mzs::pick_quad_kernel_bf16(d, hid_global); /* mzsearch_bf16.hip */
     return hid_global ? pick_quad_kernel_t<true>(d) : pick_quad_kernel_t<false>(d);
 }
 
 /* the kernels compiled for two wavefronts per SIMD (hidden states in the global array, no tied mid
  * layers); fp32: ~35 register reloads from scratch per simulation, paid back by the second wave */
 quad_kernel_t pick_quad_kernel_occ2(const mzs_dims& d) {
-    if (d.precision == MZS_PRECISION_BF16) return mzs::pick_quad_kernel_bf16(d, true, true);
+    if (d.precision != MZS_PRECISION_F32) return mzs::pick_quad_kernel_bf16(d, true, true);
     if (d.obs_dim > 64 || d.model_kind != MZS_MODEL_MLP || d.n_mid_layers != 0) return nullptr;
     if (d.state_dim == 31 && d.hidden_dim == 64) {
-        if (d.n_actions == 2) return k_search_quad<31, 2, 64, false, false, true, false, 2>;
-        if (d.n_actions == 4) return k_search_quad<31, 4, 64, false, false, true, false, 2>;
+        if (d.n_actions == 2) return k_search_quad<31, 2, 64, false, false, true, 0, 2>;
+        if (d.n_actions == 4) return k_search_quad<31, 4, 64, false, false, true, 0, 2>;
     }
     return nullptr;
 }
@@ -1177,7 +1177,8 @@ SearchPlan plan_search(const mzs_handle* h, int S, int n_games) {
             pl.ql = qg;
             pl.wpb = 4;
             std::snprintf(pl.name, sizeof pl.name, "k_search_quad<%d,%d,%d,false,%s,true,%s2 waves/SIMD>", d.state_dim, A,
-                          d.hidden_dim, d.n_mid_layers ? "true" : "false", d.precision == MZS_PRECISION_BF16 ? "bf16," : "");
+                          d.hidden_dim, d.n_mid_layers ? "true" : "false",
+                          d.precision == MZS_PRECISION_BF16 ? "bf16," : (d.precision == MZS_PRECISION_BF16X3 ? "bf16x3," : ""));
             return pl;
         }
     }
@@ -1196,7 +1197,7 @@ SearchPlan plan_search(const mzs_handle* h, int S, int n_games) {
             pl.wpb = hid_global ? wpg : wpb;
             std::snprintf(pl.name, sizeof pl.name, "k_search_quad<%d,%d,%d,false,%s,%s%s>", d.state_dim, A,
                           d.hidden_dim, d.n_mid_layers ? "true" : "false", hid_global ? "true" : "false",
-                          d.precision == MZS_PRECISION_BF16 ? ",bf16" : "");
+                          d.precision == MZS_PRECISION_BF16 ? ",bf16" : (d.precision == MZS_PRECISION_BF16X3 ? ",bf16x3" : ""));
             return pl;
         }
     }
@@ -1320,8 +1321,8 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
         if (vo.d_fc.in_w + (vo.p_v.in_w - vo.p_res.conv_a) > (size_t)kVisCache)
             return fail(MZS_E_ARG, "vision_model: convolution / batchnorm parameters exceed the LDS cache (kVisCache)");
     }
-    if (d.precision != MZS_PRECISION_F32 && d.precision != MZS_PRECISION_BF16)
-        return fail(MZS_E_ARG, "precision must be MZS_PRECISION_F32 or MZS_PRECISION_BF16");
+    if (d.precision != MZS_PRECISION_F32 && d.precision != MZS_PRECISION_BF16 && d.precision != MZS_PRECISION_BF16X3)
+        return fail(MZS_E_ARG, "precision must be MZS_PRECISION_F32, MZS_PRECISION_BF16 or MZS_PRECISION_BF16X3");
     if (d.model_kind == MZS_MODEL_LSTM && (d.n_mid_layers < 1 || d.n_mid_layers > MZS_LSTM_MAX_LAYERS))
         return fail(MZS_E_ARG, "lstm_model: 1..4 LSTM layers (n_mid_layers)");
     if (d.n_actions > 64) return fail(MZS_E_ARG, "n_actions > 64 not supported (one lane per child)");

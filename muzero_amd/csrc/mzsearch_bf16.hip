@@ -9,15 +9,16 @@
 
 namespace mzs {
 
-/* bf16 (contract "dot_bf16"): the benchmark shape and its A = 4 sibling, with or without tied mid layers */
-template <bool kHidG>
+/* bf16 (contract "dot_bf16", kPrec 1; "dot_bf16x3", kPrec 2): the benchmark shape and its A = 4 sibling, with
+ * or without tied mid layers */
+template <bool kHidG, int kPrec>
 static quad_kernel_t pick_quad_kernel_b16_t(const mzs_dims& d) {
     if (d.obs_dim > 64 || d.model_kind != MZS_MODEL_MLP) return nullptr;
     const bool mid = d.n_mid_layers != 0;
     if (d.state_dim == 31 && d.hidden_dim == 64) {
         switch (d.n_actions) {
-            case 2: return mid ? k_search_quad<31, 2, 64, false, true, kHidG, true> : k_search_quad<31, 2, 64, false, false, kHidG, true>;
-            case 4: return mid ? k_search_quad<31, 4, 64, false, true, kHidG, true> : k_search_quad<31, 4, 64, false, false, kHidG, true>;
+            case 2: return mid ? k_search_quad<31, 2, 64, false, true, kHidG, kPrec> : k_search_quad<31, 2, 64, false, false, kHidG, kPrec>;
+            case 4: return mid ? k_search_quad<31, 4, 64, false, true, kHidG, kPrec> : k_search_quad<31, 4, 64, false, false, kHidG, kPrec>;
             default: return nullptr;
         }
     }
@@ -28,14 +29,18 @@ static quad_kernel_t pick_quad_kernel_b16_occ2(const mzs_dims& d) {
     if (d.obs_dim > 64 || d.model_kind != MZS_MODEL_MLP) return nullptr;
     const bool mid = d.n_mid_layers != 0; /* packed, even the tied mid layers fit 256 registers (~12 reloads per simulation) */
     if (d.state_dim == 31 && d.hidden_dim == 64) {
-        if (d.n_actions == 2) return mid ? k_search_quad<31, 2, 64, false, true, true, true, 2> : k_search_quad<31, 2, 64, false, false, true, true, 2>;
-        if (d.n_actions == 4) return mid ? k_search_quad<31, 4, 64, false, true, true, true, 2> : k_search_quad<31, 4, 64, false, false, true, true, 2>;
+        if (d.n_actions == 2) return mid ? k_search_quad<31, 2, 64, false, true, true, 1, 2> : k_search_quad<31, 2, 64, false, false, true, 1, 2>;
+        if (d.n_actions == 4) return mid ? k_search_quad<31, 4, 64, false, true, true, 1, 2> : k_search_quad<31, 4, 64, false, false, true, 1, 2>;
     }
     return nullptr;
 }
 quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global, bool two_per_simd) {
+    if (d.precision == MZS_PRECISION_BF16X3) { /* hi + lo weight pairs: the fp32 kernel's register count, one wave per SIMD */
+        if (two_per_simd) return nullptr;
+        return hid_global ? pick_quad_kernel_b16_t<true, 2>(d) : pick_quad_kernel_b16_t<false, 2>(d);
+    }
     if (two_per_simd) return hid_global ? pick_quad_kernel_b16_occ2(d) : nullptr;
-    return hid_global ? pick_quad_kernel_b16_t<true>(d) : pick_quad_kernel_b16_t<false>(d);
+    return hid_global ? pick_quad_kernel_b16_t<true, 1>(d) : pick_quad_kernel_b16_t<false, 1>(d);
 }
 
 }  // namespace mzs

@@ -30,7 +30,7 @@ class SearchEngine:
 
     dims = (obs_dim, n_actions, state_dim, hidden_dim, n_mid_layers[, model_kind[, precision]]) — the
     shapes the reference passes to Muzero(...) (muzero_model.py:16-35; model_kind 0 = 'mlp_model', 1 =
-    'lstm_model'; precision 0 = fp32, 1 = bf16 as type_format=torch.bfloat16); discount / pb_c_* /
+    'lstm_model'; precision 0 = fp32, 1 = bf16 (fast), 2 = bf16x3 (compensated)); discount / pb_c_* /
     root_exploration_fraction are the Monte_carlo_tree_search ctor arguments
     (monte_carlo_tree_search.py:38).
     """

@@ -193,19 +193,27 @@ class Muzero:
                  learning_rate=1e-3, optimizer="adam", lr_scheduler=None, loss_type="general",
                  device="cuda", num_of_epoch=300, hidden_layer_dimensions=16,
                  number_of_hidden_layer=1, load=False, type_format=torch.float32, use_amp=False,
-                 scaler_on=False, bin_method="uniform_bin", bin_decomposition_number=10):
+                 scaler_on=False, bin_method="uniform_bin", bin_decomposition_number=10, bf16_mode="x3"):
+        """The reference's 19 arguments (muzero_model.py:16-35) plus one of ours, last: bf16_mode, what
+        type_format=torch.bfloat16 means on the device — "x3" (default): weights and layer inputs as hi + lo
+        bfloat16 pairs, three matrix products per layer, within north_star's 1e-2 of the reference on EVERY
+        fixture model (measured <= 5e-4); "fast": both rounded to one bfloat16, a quarter of the matrix
+        instructions and half the weight registers, inside 1e-2 on the CartPole checkpoints 123 / 133 only
+        (include/mzs_numeric.h "dot_bf16x3" / "dot_bf16", tests/test_bf16_oracle.py)."""
         self.reset(model_structure, observation_space_dimensions, action_space_dimensions,
                    state_space_dimensions, k_hypothetical_steps, learning_rate, optimizer,
                    lr_scheduler, loss_type, device, num_of_epoch, hidden_layer_dimensions,
                    number_of_hidden_layer, load, type_format, use_amp, scaler_on, bin_method,
-                   bin_decomposition_number)
+                   bin_decomposition_number, bf16_mode)
 
     def reset(self, model_structure=None, observation_space_dimensions=None,
               action_space_dimensions=None, state_space_dimensions=None, k_hypothetical_steps=None,
               learning_rate=1e-3, optimizer="adam", lr_scheduler=None, loss_type="general",
               device="cuda", num_of_epoch=300, hidden_layer_dimensions=64,
               number_of_hidden_layer=1, load=False, type_format=torch.float32, use_amp=False,
-              scaler_on=False, bin_method="uniform_bin", bin_decomposition_number=10):
+              scaler_on=False, bin_method="uniform_bin", bin_decomposition_number=10, bf16_mode="x3"):
+        if bf16_mode not in ("x3", "fast"):
+            raise ValueError(f"bf16_mode={bf16_mode!r}: 'x3' (compensated) or 'fast'")
         if model_structure not in (None, "mlp_model", "lstm_model", "vision_model"):
             raise NotImplementedError(f"model_structure={model_structure!r}: 'mlp_model', 'lstm_model' and "
                                       "'vision_model' (inference and search) have MI355X kernels")
@@ -232,8 +240,10 @@ class Muzero:
         # under torch.autocast; its own bf16 VALUE output collapses to -1 (inverse_transform_with_support
         # runs in bfloat16 outside autocast, muzero_model.py:903) — not reproduced, see DESIGN.md.
         self.type_format = torch.bfloat16 if type_format is torch.bfloat16 else torch.float32
-        self.precision = _lib.PRECISION_BF16 if self.type_format is torch.bfloat16 else _lib.PRECISION_F32
-        self.use_amp, self.scaler_on = self.precision == _lib.PRECISION_BF16, False
+        self.bf16_mode = bf16_mode
+        self.precision = ((_lib.PRECISION_BF16X3 if bf16_mode == "x3" else _lib.PRECISION_BF16)
+                          if self.type_format is torch.bfloat16 else _lib.PRECISION_F32)
+        self.use_amp, self.scaler_on = self.precision != _lib.PRECISION_F32, False
         self.random_tag = np.random.randint(0, 100000000)  # muzero_model.py:213 (global stream)
         self.store_loss = []
         self.bin_method, self.bin_decomposition_number = bin_method, bin_decomposition_number

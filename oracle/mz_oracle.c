@@ -32,6 +32,31 @@ static void dense_bf16(const float* W, const float* b, const float* x, int nout,
     free(xb);
 }
 
+/* contract "dot_bf16x3" (include/mzs_numeric.h): weights and inputs as hi + lo bfloat16 pairs, three
+ * mzs_dot4_bf16 per group of four k (hi hi, hi lo, lo hi), four chains of fp32 additions */
+static void dense_bf16x3(const float* W, const float* b, const float* x, int nout, int nin, int ldw, float* y) {
+    const int ng = (nin + 3) / 4;
+    unsigned short* xh = (unsigned short*)calloc((size_t)ng * 4 * 4, sizeof(unsigned short));
+    unsigned short *xl = xh + (size_t)ng * 4, *wh = xl + (size_t)ng * 4, *wl = wh + (size_t)ng * 4;
+    for (int k = 0; k < nin; ++k) mzs_bf16_split(x[k], xh + k, xl + k);
+    for (int j = 0; j < nout; ++j) {
+        const float* w = W + (size_t)j * ldw;
+        for (int k = 0; k < nin; ++k) mzs_bf16_split(w[k], wh + k, wl + k);
+        float e = b[j], o = 0.0f, s = 0.0f, t = 0.0f;
+        for (int g = 0; g < ng; g += 2) e = e + mzs_dot4_bf16(wh + 4 * g, xh + 4 * g);
+        if (ng > 1) o = mzs_dot4_bf16(wh + 4, xh + 4);
+        for (int g = 3; g < ng; g += 2) o = o + mzs_dot4_bf16(wh + 4 * g, xh + 4 * g);
+        s = mzs_dot4_bf16(wh, xl);
+        t = mzs_dot4_bf16(wl, xh);
+        for (int g = 1; g < ng; ++g) {
+            s = s + mzs_dot4_bf16(wh + 4 * g, xl + 4 * g);
+            t = t + mzs_dot4_bf16(wl + 4 * g, xh + 4 * g);
+        }
+        y[j] = (e + o) + (s + t);
+    }
+    free(xh);
+}
+
 /* contract "dot": even-k chain from the bias, odd-k chain from zero, one add.
  * W row-major [nout][ldw]. */
 static void dense_f32(const float* W, const float* b, const float* x, int nout, int nin, int ldw,
@@ -49,13 +74,16 @@ static void dense_f32(const float* W, const float* b, const float* x, int nout, 
 static int g_bf16 = 0;
 #pragma omp threadprivate(g_bf16)
 static void dense(const float* W, const float* b, const float* x, int nout, int nin, int ldw, float* y) {
-    if (g_bf16)
+    if (g_bf16 == MZS_PRECISION_BF16X3)
+        dense_bf16x3(W, b, x, nout, nin, ldw, y);
+    else if (g_bf16)
         dense_bf16(W, b, x, nout, nin, ldw, y);
     else
         dense_f32(W, b, x, nout, nin, ldw, y);
 }
-/* a weight used outside a dot (the one-hot action column): rounded like every other weight */
-static float weight_value(float w) { return g_bf16 ? mzs_bf16_round(w) : w; }
+/* a weight used outside a dot (the one-hot action column): rounded like every other weight under
+ * "dot_bf16", exact under "dot" and "dot_bf16x3" */
+static float weight_value(float w) { return g_bf16 == MZS_PRECISION_BF16 ? mzs_bf16_round(w) : w; }
 
 static void elu_inplace(float* x, int n) {
     for (int i = 0; i < n; ++i) x[i] = mzs_elu(x[i]);
@@ -259,7 +287,7 @@ void mzo_representation(const mzs_dims* d, const float* blob, const float* obs, 
     }
     mzs_blob_offsets o = mzs_blob_layout(d);
     scratch s = scratch_new(d);
-    g_bf16 = d->precision == MZS_PRECISION_BF16;
+    g_bf16 = d->precision; /* 0, MZS_PRECISION_BF16, MZS_PRECISION_BF16X3 */
     for (int i = 0; i < B; ++i)
         repr_one(d, blob, &o, obs + (size_t)i * d->obs_dim, hidden + (size_t)i * d->state_dim, &s);
     free(s.t);
@@ -273,7 +301,7 @@ void mzo_dynamics(const mzs_dims* d, const float* blob, const float* hidden,
     }
     mzs_blob_offsets o = mzs_blob_layout(d);
     scratch s = scratch_new(d);
-    g_bf16 = d->precision == MZS_PRECISION_BF16;
+    g_bf16 = d->precision; /* 0, MZS_PRECISION_BF16, MZS_PRECISION_BF16X3 */
     for (int i = 0; i < B; ++i)
         dyn_one(d, blob, &o, hidden + (size_t)i * d->state_dim, action[i], reward + i,
                 next_hidden + (size_t)i * d->state_dim, &s);
@@ -288,7 +316,7 @@ void mzo_prediction(const mzs_dims* d, const float* blob, const float* hidden, i
     }
     mzs_blob_offsets o = mzs_blob_layout(d);
     scratch s = scratch_new(d);
-    g_bf16 = d->precision == MZS_PRECISION_BF16;
+    g_bf16 = d->precision; /* 0, MZS_PRECISION_BF16, MZS_PRECISION_BF16X3 */
     for (int i = 0; i < B; ++i)
         pred_one(d, blob, &o, hidden + (size_t)i * d->state_dim, policy + (size_t)i * d->n_actions,
                  value + i, &s);
@@ -470,7 +498,7 @@ int mzo_search(const mzo_search_cfg* cfg, const float* blob, const mzo_table_mod
         T.root_prior = (double*)malloc(sizeof(double) * (size_t)d->n_actions);
         T.hidden = (float*)malloc(sizeof(float) * (size_t)(S + 1) * mzs_hidden_floats(d));
         scratch sc = scratch_new(d);
-        g_bf16 = d->precision == MZS_PRECISION_BF16; /* threadprivate */
+        g_bf16 = d->precision; /* 0, MZS_PRECISION_BF16, MZS_PRECISION_BF16X3 */ /* threadprivate */
 #pragma omp for schedule(static)
         for (int g = 0; g < G; ++g) {
             int r = search_one(cfg, blob, &bo, tbl, obs, dirichlet,

@@ -1,5 +1,5 @@
-"""GPU parity of the bf16 variant (Muzero(type_format=torch.bfloat16); include/mzs_numeric.h
-"dot_bf16"): the HIP kernels — v_mfma_f32_4x4x4_16B_bf16 in k_search_quad<..., bf16>, the software
+"""GPU parity of the bf16 variants (Muzero(type_format=torch.bfloat16); include/mzs_numeric.h
+"dot_bf16x3" = precision 2, the default, and "dot_bf16" = precision 1, bf16_mode="fast"): the HIP kernels — v_mfma_f32_4x4x4_16B_bf16 in k_search_quad<..., bf16>, the software
 restatement of that instruction in the any-shape kernels — against the bf16 oracle, bit for bit,
 through the C-ABI.  Accuracy against the reference (1e-2) is the oracle's: tests/test_bf16_oracle.py."""
 import numpy as np
@@ -12,23 +12,28 @@ from test_gpu_parity import FULL_WANT, assert_search_equals_oracle, same_bits
 pytestmark = pytest.mark.gpu
 
 
-def make_engine(d, G, S, gamma=0.997, frac=0.25, engine="fused"):
+PRECISIONS = [1, 2]          # MZS_PRECISION_BF16 (fast), MZS_PRECISION_BF16X3 (compensated)
+SUFFIX = {1: ",bf16>", 2: ",bf16x3>"}
+
+
+def make_engine(d, G, S, gamma=0.997, frac=0.25, engine="fused", prec=1):
     from muzero_amd import _lib
     from muzero_amd.engine import SearchEngine
-    return SearchEngine((d.obs_dim, d.n_actions, d.state_dim, d.hidden_dim, d.n_mid_layers, d.model_kind, 1),
+    return SearchEngine((d.obs_dim, d.n_actions, d.state_dim, d.hidden_dim, d.n_mid_layers, d.model_kind, prec),
                         max_games=G, max_simulations=S, discount=gamma, root_exploration_fraction=frac,
                         engine=_lib.ENGINE_FUSED if engine == "fused" else _lib.ENGINE_FUSED_GENERIC)
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("tag", MODEL_TAGS)
-def test_bf16_inference_kernels_equal_oracle(tag):
+def test_bf16_inference_kernels_equal_oracle(tag, prec):
     """initial / recurrent / prediction inference (any-shape kernels: mzs_dot4_bf16 in software),
-    MLP and LSTM models."""
+    MLP and LSTM models, both bf16 contracts."""
     from oracle import mz_oracle as mzo
     d, blob = fixture_weights(tag)
-    db = bf16_dims(d)
+    db = bf16_dims(d, prec)
     mv = load_golden(f"model_L2_{tag}.npz")
-    eng = make_engine(d, 1, 0)
+    eng = make_engine(d, 1, 0, prec=prec)
     eng.set_weights(blob)
     hid, pol, val = [t.cpu().numpy() for t in eng.initial_inference(mv["obs"])]
     oh, op, ov = mzo.initial_inference(db, blob, mv["obs"])
@@ -42,6 +47,8 @@ def test_bf16_inference_kernels_equal_oracle(tag):
     eng.close()
 
 
+FAST_WIDE = {}     # tag -> kernel-name prefix of the fast-bf16 wide / LSTM kernels (filled in when they exist)
+
 BF16_SEARCHES = [("search_tag123_S50.npz", "tag123"), ("search_tag123_S11.npz", "tag123"),
                  ("search_tag123_S1.npz", "tag123"), ("search_tag123_S0.npz", "tag123"),
                  ("search_tag123_S50_notrain.npz", "tag123"), ("search_tag123_S50_wide.npz", "tag123"),
@@ -50,9 +57,10 @@ BF16_SEARCHES = [("search_tag123_S50.npz", "tag123"), ("search_tag123_S11.npz", 
                  ("search_lstmA_S50.npz", "lstmA")]
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("engine", ["fused", "generic"])
 @pytest.mark.parametrize("fname,tag", BF16_SEARCHES)
-def test_bf16_search_equals_oracle(fname, tag, engine):
+def test_bf16_search_equals_oracle(fname, tag, engine, prec):
     """Whole searches on the fixtures' inputs: the MFMA kernel (tag123: L = 0; tag133: tied mid
     layers; synA4: four actions) and the any-shape kernel (everything else, and every shape under
     engine="generic") == bf16 oracle on every output bit, hidden states included."""
@@ -62,16 +70,18 @@ def test_bf16_search_equals_oracle(fname, tag, engine):
     S, G = int(fx["S"]), len(fx["seed"])
     dirichlet, noise = fixture_streams(fx)
     train = bool(fx["train"])
-    eng = make_engine(d, G, S, float(fx["gamma"]), float(fx["frac"]), engine)
+    eng = make_engine(d, G, S, float(fx["gamma"]), float(fx["frac"]), engine, prec)
     eng.set_weights(blob)
     name = eng.search_kernel_name(S)
     if engine == "fused" and tag in ("tag123", "tag133", "synA4"):
-        assert name.startswith("k_search_quad<") and name.endswith(",bf16>"), name
+        assert name.startswith("k_search_quad<") and name.endswith(SUFFIX[prec]), name
+    elif engine == "fused" and prec == 1 and tag in FAST_WIDE:
+        assert name.startswith(FAST_WIDE[tag]), name
     else:
         assert name == "k_search_fused<false>", name
     eng.search(fx["obs"], dirichlet if train and S > 0 else None, noise if S > 0 else None, S, train)
     out, tree = eng.results_host(), eng.tree_host()
-    ref = mzo.search(bf16_dims(d), blob, S, float(fx["gamma"]), float(fx["frac"]), fx["pbc_table"], obs=fx["obs"],
+    ref = mzo.search(bf16_dims(d, prec), blob, S, float(fx["gamma"]), float(fx["frac"]), fx["pbc_table"], obs=fx["obs"],
                      dirichlet=dirichlet, noise=noise, train=train, want=FULL_WANT)
     assert not tree["status"].any()
     assert_search_equals_oracle(out, tree, ref)
@@ -80,8 +90,9 @@ def test_bf16_search_equals_oracle(fname, tag, engine):
 
 @pytest.mark.parametrize("shape", [(8, 4, 31, 64, 0), (4, 2, 31, 64, 0), (4, 2, 31, 64, 4), (8, 4, 31, 64, 1),
                                    (64, 2, 31, 64, 0), (1, 2, 31, 64, 2)])
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("G,S", [(37, 50), (5, 7), (1, 50), (11, 120)])
-def test_bf16_quad_shapes_vs_oracle(shape, G, S):
+def test_bf16_quad_shapes_vs_oracle(shape, G, S, prec):
     """Every shape the bf16 MFMA kernel is instantiated for, ragged game counts (partial waves /
     blocks), observation widths 1 .. 64 (partial and full groups of four in the input layer), a
     deep search (hidden states in the global array), seeded random weights: == oracle on every bit."""
@@ -95,19 +106,20 @@ def test_bf16_quad_shapes_vs_oracle(shape, G, S):
     A = shape[1]
     obs = rs.uniform(-1, 1, size=(G, shape[0])).astype(np.float32)
     dirichlet, noise = rng.noise_streams(np.arange(G) + 77, A, S, 0.25, True)
-    eng = make_engine(d, G, S)
+    eng = make_engine(d, G, S, prec=prec)
     eng.set_weights(blob)
-    assert eng.search_kernel_name(S).endswith(",bf16>")
+    assert eng.search_kernel_name(S).endswith(SUFFIX[prec])
     eng.search(obs, dirichlet, noise, S, True)
     out, tree = eng.results_host(), eng.tree_host()
-    ref = mzo.search(bf16_dims(d), blob, S, 0.997, 0.25, eng.pbc, obs=obs, dirichlet=dirichlet, noise=noise,
+    ref = mzo.search(bf16_dims(d, prec), blob, S, 0.997, 0.25, eng.pbc, obs=obs, dirichlet=dirichlet, noise=noise,
                      train=True, want=FULL_WANT)
     assert not tree["status"].any()
     assert_search_equals_oracle(out, tree, ref)
     eng.close()
 
 
-def test_bf16_full_size_4096_games_vs_oracle():
+@pytest.mark.parametrize("prec", PRECISIONS)
+def test_bf16_full_size_4096_games_vs_oracle(prec):
     """BASELINE workload size in bf16: 4096 games x 50 simulations, three launches in a row (race
     screen), each == oracle on visit counts, root-value bits, expanded leaves and value sums."""
     from muzero_amd import rng
@@ -116,9 +128,9 @@ def test_bf16_full_size_4096_games_vs_oracle():
     G, S, A = 4096, 50, 2
     obs = np.random.RandomState(1000).uniform(-0.05, 0.05, size=(G, 4)).astype(np.float32)
     dirichlet, noise = rng.noise_streams(np.arange(G), A, S, 0.25, True)
-    ref = mzo.search(bf16_dims(d), blob, S, 0.997, 0.25, rng.pbc_table(S), obs=obs, dirichlet=dirichlet, noise=noise,
+    ref = mzo.search(bf16_dims(d, prec), blob, S, 0.997, 0.25, rng.pbc_table(S), obs=obs, dirichlet=dirichlet, noise=noise,
                      train=True, n_threads=8, want=("visits", "root_value", "consumed", "node_vsum", "sim_leaf"))
-    eng = make_engine(d, G, S)
+    eng = make_engine(d, G, S, prec=prec)
     eng.set_weights(blob)
     for _ in range(3):
         eng.search(obs, dirichlet, noise, S, True)
@@ -179,7 +191,7 @@ def test_bf16_handle_trains_in_fp32_and_refreshes_rounded_weights():
     dims = tuple(int(x) for x in fx["dims"])
     inp = step_inputs(fx, 0)
     outs = []
-    for prec in (0, 1):
+    for prec in (0, 1, 2):
         eng = SearchEngine(dims[:5] + (0, prec), max_games=1, max_simulations=0)
         eng.set_weights(fx["blob0"])
         tr = Trainer(eng, int(fx["K"]), int(fx["B"]), "adam", 0.01)
@@ -187,20 +199,23 @@ def test_bf16_handle_trains_in_fp32_and_refreshes_rounded_weights():
                 inp["is_ratio"])
         torch.cuda.synchronize()
         outs.append((tr.grad.cpu().numpy(), tr.weights(), eng))
-    assert same_bits(outs[0][0], outs[1][0]) and same_bits(outs[0][1], outs[1][1])
-    blob1, eng = outs[1][1], outs[1][2]
-    assert not np.array_equal(blob1, fx["blob0"])
     mv = load_golden("model_L2_tag123.npz")
-    d = mzo.dims(*dims[:5], 0, 1)
-    rew, nh, pol, val = [t.cpu().numpy() for t in eng.recurrent_inference(mv["hidden"], mv["action"])]
-    orr, onh, op, ov = mzo.recurrent_inference(d, blob1, mv["hidden"], mv["action"])
-    assert same_bits(rew, orr) and same_bits(nh, onh) and same_bits(pol, op) and same_bits(val, ov)
-    outs[0][2].close(), eng.close()
+    for prec in (1, 2):
+        assert same_bits(outs[0][0], outs[prec][0]) and same_bits(outs[0][1], outs[prec][1])
+        blob1, eng = outs[prec][1], outs[prec][2]
+        assert not np.array_equal(blob1, fx["blob0"])
+        d = mzo.dims(*dims[:5], 0, prec)
+        rew, nh, pol, val = [t.cpu().numpy() for t in eng.recurrent_inference(mv["hidden"], mv["action"])]
+        orr, onh, op, ov = mzo.recurrent_inference(d, blob1, mv["hidden"], mv["action"])
+        assert same_bits(rew, orr) and same_bits(nh, onh) and same_bits(pol, op) and same_bits(val, ov)
+    for o in outs:
+        o[2].close()
 
 
-def test_bf16_muzero_drop_in():
-    """Muzero(type_format=torch.bfloat16) + Monte_carlo_tree_search.run: the reference's call
-    sequence, bf16 kernels underneath, results == bf16 oracle; within 1e-2 of the fp32 reference."""
+@pytest.mark.parametrize("mode,prec", [("x3", 2), ("fast", 1)])
+def test_bf16_muzero_drop_in(mode, prec):
+    """Muzero(type_format=torch.bfloat16[, bf16_mode="fast"]) + Monte_carlo_tree_search.run: the reference's
+    call sequence, bf16 kernels underneath, results == bf16 oracle; within 1e-2 of the fp32 reference."""
     import torch
     from muzero_amd.model import Muzero
     from muzero_amd.search import Monte_carlo_tree_search
@@ -210,12 +225,12 @@ def test_bf16_muzero_drop_in():
     fx = load_golden("search_tag123_S50.npz")
     mz = Muzero(observation_space_dimensions=4, action_space_dimensions=2, state_space_dimensions=31,
                 hidden_layer_dimensions=64, number_of_hidden_layer=0, k_hypothetical_steps=5,
-                type_format=torch.bfloat16)
-    assert mz.use_amp and mz.dims[-1] == 1
+                type_format=torch.bfloat16, bf16_mode=mode)
+    assert mz.use_amp and mz.dims[-1] == prec
     mz.set_weights(blob)
     mcts = Monte_carlo_tree_search(discount=0.997)
     dirichlet, noise = fixture_streams(fx)
-    ref = mzo.search(bf16_dims(d), blob, 50, 0.997, 0.25, fx["pbc_table"], obs=fx["obs"][:8], dirichlet=dirichlet[:8],
+    ref = mzo.search(bf16_dims(d, prec), blob, 50, 0.997, 0.25, fx["pbc_table"], obs=fx["obs"][:8], dirichlet=dirichlet[:8],
                      noise=noise[:8], train=True)
     for g in range(8):
         np.random.seed(int(fx["seed"][g]))
