@@ -51,8 +51,8 @@ __device__ __forceinline__ f32x4 lstm_cell0_4(const f32x4 gi, const f32x4 gg, co
  * projections): phases 0..3, so every head starts in phase 0; the o unit's request is the next
  * head's Linear (KN rows).  trow: the game's 64-float row for the Linear's output (the B operand
  * of the gates). */
-template <int KIN, int H, int KN>
-__device__ __forceinline__ f32x4 lstm_head_quad(WideStream& st, const LstmHeadTabs& ht, const float* xrow, int action,
+template <int KIN, int H, int KN, class ST>
+__device__ __forceinline__ f32x4 lstm_head_quad(ST& st, const LstmHeadTabs& ht, const float* xrow, int action,
                                                 float* trow, const QuadLane& q) {
     static_assert(H <= 64 && KIN <= 64, "single-chunk units");
     const auto ld4 = [&](const float* p) {
@@ -102,8 +102,8 @@ __device__ __forceinline__ void lstm_representation_quad(const Model& m, const W
 
 /* Dynamics_function: reward head then next-state head (its raw LSTM output is the new hidden
  * state, lstm:49-51) */
-template <int SD, int H>
-__device__ __forceinline__ float lstm_dynamics_quad(WideStream& st, const LstmTabs& T, const WideBufs& Bf,
+template <int SD, int H, class ST>
+__device__ __forceinline__ float lstm_dynamics_quad(ST& st, const LstmTabs& T, const WideBufs& Bf,
                                                     const QuadLane& q, int action, float* hdst, int hid_stride) {
     float* xrow = Bf.xin + q.c * kWideXStride;
     float* trow = Bf.trunk + q.c * kWideTStride;
@@ -121,8 +121,8 @@ __device__ __forceinline__ float lstm_dynamics_quad(WideStream& st, const LstmTa
 }
 
 /* Prediction_function: policy head, value head */
-template <int SD, int H>
-__device__ __forceinline__ float lstm_prediction_quad(WideStream& st, const LstmTabs& T, const WideBufs& Bf,
+template <int SD, int H, class ST>
+__device__ __forceinline__ float lstm_prediction_quad(ST& st, const LstmTabs& T, const WideBufs& Bf,
                                                       const QuadLane& q, int n_actions, f32x4* prior) {
     float* xrow = Bf.xin + q.c * kWideXStride;
     float* trow = Bf.trunk + q.c * kWideTStride;

@@ -98,8 +98,9 @@ struct WideStream {
     WideGlobalPtr img; /* image 0 + this lane's neuron */
     int n_img, next_img;
     float w[kBufs][64];
-    __device__ __forceinline__ void init(const float* images, int n_images, int lane) {
-        img = (WideGlobalPtr)images + 4 * quad_neuron_of_lane(lane);
+    /* images: the handle's image buffer; image0: index of the first image of this wave's share */
+    __device__ __forceinline__ void init(const float* images, int image0, int n_images, int lane) {
+        img = (WideGlobalPtr)images + (size_t)image0 * kImageFloats + 4 * quad_neuron_of_lane(lane);
         n_img = n_images;
         next_img = 0;
     }

@@ -164,8 +164,8 @@ __device__ __forceinline__ void pair_unit(WideStream& st, const float* __restric
 /* this wave's half of a trunk layer + ELU for the eight games: reads `in` rows, writes columns
  * [64 u, 64 u + 64) of the `out` rows (a different buffer: the partner still reads `in`).
  * onehot: this wave's half of the [A][128] action rows, or null; act: the games' actions. */
-template <int K, int I>
-__device__ __forceinline__ void pair_trunk(WideStream& st, const float* bias_half, const float* onehot_half,
+template <int K, int I, class ST>
+__device__ __forceinline__ void pair_trunk(ST& st, const float* bias_half, const float* onehot_half,
                                            const int* act, const float* in, int in_stride, float* out, int u,
                                            const QuadLane& q, unsigned long long* dg = nullptr) {
     f32x4 acc[2];
@@ -187,8 +187,8 @@ __device__ __forceinline__ void pair_trunk(WideStream& st, const float* bias_hal
  * new hidden states in P.xin and in the global rows hdst[s] (wave 1 stores them), P.rew / P.val /
  * P.pri, barrier behind them.  kRoot: prediction only (the hidden states come from the
  * representation net).  Stream phase at entry: 0 (dynamics first) or 1 (kRoot). */
-template <int SD, int H, int NA, bool kRoot>
-__device__ __forceinline__ void pair_model(WideStream& st, const Model& m, const WideTabs& T, const PairBufs& P, int u,
+template <int SD, int H, int NA, bool kRoot, class ST>
+__device__ __forceinline__ void pair_model(ST& st, const Model& m, const WideTabs& T, const PairBufs& P, int u,
                                            const QuadLane& q, float* const (&hdst)[2],
                                            unsigned long long* dg = nullptr) {
     static_assert(H > 64 && H <= 128 && SD <= 64, "two trunk groups, one chunk of state inputs");

@@ -106,6 +106,9 @@ __device__ __forceinline__ bool redo_skip_quad(const SearchParams& p, int g0) {
 
 /* bf16 instantiations of k_search_quad (mzsearch_bf16.hip); nullptr: the shape has none */
 quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global, bool two_per_simd = false);
+/* "dot_bf16" instantiations of k_search_quadw2 / k_search_quadl (mzsearch_bf16.hip) for the shapes the fp32
+ * pickers of mzsearch.hip accept */
+quad_kernel_t pick_wide_kernel_bf16(const mzs_dims& d);
 
 /* ------------------------------------------------------------------------------
  * Quad fused engine (mzs_quad.h): four games per wavefront, dense layers on

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mzs_search_kernels.h"
+#include "mzs_wide_kernels.h"
 
 namespace mzs {
 
@@ -41,6 +42,16 @@ quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global, bool two
     }
     if (two_per_simd) return hid_global ? pick_quad_kernel_b16_occ2(d) : nullptr;
     return hid_global ? pick_quad_kernel_b16_t<true, 1>(d) : pick_quad_kernel_b16_t<false, 1>(d);
+}
+
+/* the weight-stream kernels on the bf16 stream (mzs_quadw_bf16.h): the wide MLP of experiments 127 / 128 and
+ * the one-layer 'lstm_model' shape */
+quad_kernel_t pick_wide_kernel_bf16(const mzs_dims& d) {
+    if (d.model_kind == MZS_MODEL_MLP && d.state_dim == 61 && d.hidden_dim == 128 && d.n_actions == 2)
+        return k_search_quadw2<61, 2, 128, true>;
+    if (d.model_kind == MZS_MODEL_LSTM && d.state_dim == 31 && d.hidden_dim == 64 && d.n_actions == 2)
+        return k_search_quadl<31, 2, 64, true>;
+    return nullptr;
 }
 
 }  // namespace mzs
