@@ -109,9 +109,20 @@ __device__ __forceinline__ void wide_quarter_b(const unsigned (&cur)[32], const 
 
 /* the matrix work of one chunk with the requests of the stream's next chunk (phase IN, KV rows) spread
  * through it, two ahead of each quarter */
+constexpr bool kSpreadRequestsB = true;  /* true: two requests ahead of each quarter (tag 127: 0.603 ms); false: all eight ahead of the block (0.622) */
 template <int K, int k0, int IN, int KV, int NS>
 __device__ __forceinline__ void wide_block_b(WideStreamB& st, const unsigned (&cur)[32], const WideXB (&x)[NS],
                                              f32x4 (&e)[NS], f32x4 (&o)[NS]) {
+    if constexpr (!kSpreadRequestsB) {
+        st.template load<IN, KV>();
+        __builtin_amdgcn_sched_barrier(0);
+        wide_quarter_b<K, k0, 0, NS>(cur, x, e, o);
+        wide_quarter_b<K, k0, 1, NS>(cur, x, e, o);
+        wide_quarter_b<K, k0, 2, NS>(cur, x, e, o);
+        wide_quarter_b<K, k0, 3, NS>(cur, x, e, o);
+        __builtin_amdgcn_sched_barrier(0);
+        return;
+    }
     st.template load_part<IN, KV, 0>();
     __builtin_amdgcn_sched_barrier(0);
     wide_quarter_b<K, k0, 0, NS>(cur, x, e, o);
