@@ -140,8 +140,12 @@ __device__ __forceinline__ void vis_conv3(const float* w, const float* in, int C
  * sum is -0 only if both addends are), so adding it and skipping it, as the contract words it, are the same
  * for finite weights.  Measured on the 49 x 49 stage: 800 cycles per 64 outputs with the bounds tests and
  * selects of the plain form (~130 instructions for 9 taps), a third of that in this form. */
-template <int C>
-__device__ __forceinline__ void vis_bn_relu_pad(const float* cw, const mzs_vis_bn& bn, const float* in, int S, float* pad,
+/* WP: where the parameters are read from — a pointer into the LDS cache (const float*), or the blob itself
+ * through the constant address space (VisConstPtr): the addresses are uniform, so the loads become scalar
+ * loads and the weights reach the fma chains as scalar operands (k_search_vis4) */
+typedef const __attribute__((address_space(4))) float* VisConstPtr;
+template <int C, class WP>
+__device__ __forceinline__ void vis_bn_relu_pad(WP cw, const mzs_vis_bn& bn, const float* in, int S, float* pad,
                                                 int lane) {
     const int P = S + 2, n = S * S, np = P * P;
     const float inv_p = 1.0f / (float)P; /* q / P below: q < 2601, P <= 51, exact with the half offset */
@@ -170,8 +174,8 @@ __device__ __forceinline__ void vis_bn_relu_pad(const float* cw, const mzs_vis_b
     wave_sync();
 }
 
-template <int C, bool kHoist>
-__device__ __forceinline__ void vis_conv3_pad(const float* cw, size_t w_off, const float* pad, int S, float* out,
+template <int C, bool kHoist, class WP>
+__device__ __forceinline__ void vis_conv3_pad(WP cw, size_t w_off, const float* pad, int S, float* out,
                                               int lane) {
     const int P = S + 2, n = S * S, np = P * P;
     /* kHoist (the representation: up to 38 passes per stage): the C x C x 9 weights in registers for all passes;
@@ -214,8 +218,8 @@ __device__ __forceinline__ void vis_conv3_pad(const float* cw, size_t w_off, con
 
 /* out [CO][7][7] = relu(batchnorm(conv3x3(in [CI][7][7]))), stride 1, padding 1: the dynamics net's first
  * stage (one pass: 49 pixels), a lane per pixel with its CI x 9 taps read once for all CO chains, as above */
-template <int CI, int CO>
-__device__ __forceinline__ void vis_conv3_bn(const float* cw, size_t w_off, const mzs_vis_bn& bn, const float* in,
+template <int CI, int CO, class WP>
+__device__ __forceinline__ void vis_conv3_bn(WP cw, size_t w_off, const mzs_vis_bn& bn, const float* in,
                                              float* out, int lane) {
     constexpr int S = MZS_VIS_S4, n = S * S;
     const bool live = lane < n;
@@ -251,8 +255,8 @@ __device__ __forceinline__ void vis_conv3_bn(const float* cw, size_t w_off, cons
 /* x += conv_a(R(conv_b(R(conv_a(R(x)))))), R = relu(batchnorm(.)); x [C][S][S]; t1, t2 scratch.  The block's
  * parameters sit at `base` of the cache in mzs_vis_res_layout's order (conv_a, conv_b, batchnorm): plain
  * scalars — offsets selected out of the layout structs ended up as indexed loads from scratch memory */
-template <bool kHoist = false>
-__device__ __forceinline__ void vis_res_block(const float* blob, size_t base, int C, float* x, int S, float* t1,
+template <bool kHoist = false, class WP>
+__device__ __forceinline__ void vis_res_block(WP blob, size_t base, int C, float* x, int S, float* t1,
                                               float* t2, int lane) {
     const int n = S * S;
     const size_t cc9 = (size_t)C * C * 9;

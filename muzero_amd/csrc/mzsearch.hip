@@ -22,6 +22,7 @@
 #include "../../include/mzs_crmath.h"
 #include "mzs_device.h"
 #include "mzs_quad.h"
+#include "mzs_vision_mm.h"
 #include "mzs_search_kernels.h"
 #include "mzs_quadw.h"
 #include "mzs_quadw2.h"
@@ -217,6 +218,132 @@ __global__ void __launch_bounds__(256, kVision ? kVisWaves : 4) k_search_fused(c
     }
 
     /* tree -> HBM structure of arrays; results (mcts.py:215-222) */
+    const size_t row = (size_t)g * p.t.stride;
+    for (int n = lane; n < p.n_nodes; n += kWave) {
+        const Node nd = L.nodes[n];
+        p.t.visit[row + n] = nd.visit;
+        p.t.vsum[row + n] = nd.vsum;
+        p.t.prior[row + n] = nd.prior;
+        p.t.reward[row + n] = nd.reward;
+        p.t.child_base[row + n] = L.cb[n];
+    }
+    if (lane < A) {
+        p.r.visits[(size_t)g * A + lane] = L.nodes[1 + lane].visit;
+        if (p.r.visits_sink) p.r.visits_sink[(size_t)g * A + lane] = L.nodes[1 + lane].visit;
+        p.r.root_prior[(size_t)g * A + lane] = s.root_prior;
+    }
+    if (lane == 0) {
+        const Node r = L.nodes[0];
+        const float rv = r.visit == 0 ? 0.0f : r.vsum / (float)r.visit;
+        p.r.root_value[g] = rv;
+        if (p.r.root_value_sink) p.r.root_value_sink[g] = rv;
+        p.r.consumed[g] = s.consumed;
+        p.r.path_len[g] = s.path_total;
+        p.t.minmax[2 * (size_t)g] = s.mn;
+        p.t.minmax[2 * (size_t)g + 1] = s.mx;
+        p.t.status[g] = s.status;
+        if (s.status && p.overflow) *p.overflow = 1;
+    }
+}
+
+/* ------------------------------------------------------------------------------
+ * k_search_vis4: the simulations of a 'vision_model' search, four games per workgroup: the tree work and
+ * the convolutions one game per wavefront exactly as in k_search_fused (mzs_vision.h), the three head
+ * MLPs of a simulation on the matrix core for the block's four games at once, one head per wavefront
+ * (mzs_vision_mm.h).  Every wave of the block reaches both barriers of every simulation: waves whose
+ * game lies past n_games replay the last game and write nothing; a redo pass replays whole blocks.
+ * The roots come from k_inference<initial, vision> as for k_search_fused.
+ * ---------------------------------------------------------------------------- */
+template <int kWavesPerSimd>
+__global__ void __launch_bounds__(256, kWavesPerSimd) k_search_vis4(const SearchParams p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int lane = lane_id();
+    const int wave = threadIdx.x >> 6;
+    if (redo_skip_block(p, 4)) return;
+    WaveLds L = carve(smem + (size_t)wave * p.lds.bytes, p.lds);
+    const Model& m = p.m;
+    float* shared = reinterpret_cast<float*>(smem + (size_t)4 * p.lds.bytes);
+    L.vc = shared;
+    const VisMmLds M = vis_mm_carve(shared + kVisCache, m.H, m.Sd, m.A);
+    vis_cache_load_block(m.blob, vis_offsets(m), L.vc); /* ends in the block's barrier */
+    const int g_raw = blockIdx.x * 4 + wave;
+    const bool live = g_raw < p.n_games;
+    const int g = live ? g_raw : p.n_games - 1;
+    const int A = m.A, S = p.S;
+
+    SearchConst c;
+    c.A = A;
+    c.S = S;
+    c.n_nodes = p.n_nodes;
+    c.g32 = p.g32;
+    c.pbc = p.pbc;
+    c.noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
+    c.noise_cap = p.noise ? p.noise_avail : 0;
+
+    SearchState s;
+    s.mn = __builtin_inff();
+    s.mx = -__builtin_inff();
+    s.consumed = 0;
+    s.path_total = 0;
+    s.status = 0;
+    s.root_prior = 0.0;
+    if (c.noise) {
+        noise_refill(c, s, lane);
+    } else {
+        s.win_base = 0;
+        s.win = 0.0;
+    }
+    for (int n = lane; n < p.n_nodes; n += kWave) {
+        Node z;
+        z.visit = 0;
+        z.vsum = 0.0f;
+        z.prior = 0.0f;
+        z.reward = 0.0f;
+        L.nodes[n] = z;
+        L.cb[n] = 0;
+    }
+    wave_sync();
+
+    float* hid_g = p.t.hidden + (size_t)g * (p.t.max_sims + 1) * p.t.hid_stride;
+    Pair pol = pair_from_global(p.t_root_policy + (size_t)g * A, A, lane);
+    wave_expand(c, L, 0, 0, 0.0f, pol, lane);
+    if (lane < A) {
+        const float pr = L.nodes[1 + lane].prior;
+        if (p.train && S > 0)
+            s.root_prior = (double)(pr * p.omf32) + p.dirichlet[(size_t)g * A + lane] * p.frac;
+        else
+            s.root_prior = (double)pr;
+    }
+    float* hx_rew = M.hx + (size_t)(0 * 4 + wave) * M.hxs;
+    float* hx_val = M.hx + (size_t)(1 * 4 + wave) * M.hxs;
+    float* hx_pol = M.hx + (size_t)(2 * 4 + wave) * M.hxs;
+
+    for (int sim = 0; sim < S; ++sim) {
+        int depth, action, pbase;
+        const int leaf = wave_select(c, s, L, &depth, &action, &pbase, lane);
+        const int e_new = sim + 1;
+        const int e_parent = (pbase - 1) / A;
+        const float* hp = hid_g + (size_t)e_parent * p.t.hid_stride;
+        for (int k = lane; k < m.hid; k += kWave) L.xh[k] = hp[k];
+        wave_sync();
+        /* dead waves replay the last game: they must not store into its rows while its owner reads them */
+        vis_dynamics_conv(m, L, action, live ? hid_g + (size_t)e_new * p.t.hid_stride : nullptr, hx_rew, lane);
+        vis_prediction_conv(m, L, hx_val, hx_pol, lane);
+        __syncthreads();
+        if (wave < 3) vis_mm_head<(kWavesPerSimd >= 4 ? 2 : 4)>(m, M, wave, lane);
+        __syncthreads();
+        const float reward = seg_support_scalar(M.lg + (size_t)(0 * 4 + wave) * M.ls, m.Sd, lane);
+        wave_sync();
+        const float value = seg_support_scalar(M.lg + (size_t)(1 * 4 + wave) * M.ls, m.Sd, lane);
+        wave_sync();
+        pol = seg_softmax(seg_load(M.lg + (size_t)(2 * 4 + wave) * M.ls, A, lane));
+        wave_sync();
+        wave_expand(c, L, leaf, e_new, reward, pol, lane);
+        if (lane == 0 && live) p.t.sim_leaf[(size_t)g * p.t.max_sims + sim] = leaf;
+        wave_backup(c, s, L, depth, value, lane);
+    }
+    if (!live) return;
+
     const size_t row = (size_t)g * p.t.stride;
     for (int n = lane; n < p.n_nodes; n += kWave) {
         const Node nd = L.nodes[n];
@@ -668,7 +795,9 @@ void describe_model(const mzs_dims& d, Model* m, StoreBuilder* sb) {
     m->p_heads = sb->add(H, H, round_up(m->seg_value + Sd, 64));
 }
 
-LdsLayout make_lds_layout(const Model& m, int n_nodes, int S, bool vis_sims_only = false) {
+/* vis_sims_only (vision model): 0 = every map of the representation, 1 = the simulations of k_search_fused,
+ * 2 = the simulations of k_search_vis4 */
+LdsLayout make_lds_layout(const Model& m, int n_nodes, int S, int vis_sims_only = 0) {
     LdsLayout l;
     int off = round_up(n_nodes * (int)sizeof(Node), 16);
     l.off_cb = off;
@@ -688,7 +817,10 @@ LdsLayout make_lds_layout(const Model& m, int n_nodes, int S, bool vis_sims_only
     }
     if (m.kind == MZS_MODEL_VISION) { /* mzs_vision.h: three maps of up to 49 x 49 floats, logits behind the third's head */
         off = l.off_xh + kVisXh * 4;
-        if (vis_sims_only) { /* dynamics / prediction on 7 x 7 maps: 4 x 49 floats, H activations, logits at ob + 256 */
+        if (vis_sims_only == 2) { /* k_search_vis4: the 7 x 7 maps only (the head MLPs live in block-shared LDS) */
+            act = 256;
+            ob = 160;
+        } else if (vis_sims_only) { /* dynamics / prediction on 7 x 7 maps: 4 x 49 floats, H activations, logits at ob + 256 */
             act = act > 256 ? act : 256;
             ob = 256 + 128;
         } else {
@@ -909,6 +1041,21 @@ int launch_quad(quad_kernel_t kernel, const SearchParams& p, const QuadLayout& q
 /* what mzs_search launches for a search of S simulations on this handle: the one place the
  * dispatch lives (mzs_search and mzs_search_kernel_name both read it) */
 enum { kPlanGeneric = 0, kPlanQuad = 1, kPlanStream = 2 };
+
+/* vision model: the simulations run in k_search_vis4 (head MLPs on the matrix core, four games per block) when
+ * the head buffers fit its LDS plan; MZS_ENGINE_FUSED_GENERIC keeps k_search_fused (the cross-check) */
+bool vis4_ok(const mzs_handle* h, int n_games) {
+    const mzs_dims& d = h->cfg.dims;
+    if (!(d.model_kind == MZS_MODEL_VISION && h->cfg.engine == MZS_ENGINE_FUSED && d.hidden_dim <= 256 &&
+          d.state_dim <= 128 && d.n_actions <= 64))
+        return false;
+    /* Measured (tools/bench_vision.py, visA, 50 simulations; profiles/r3_vision_summary.md): up to two blocks
+     * per CU k_search_vis4 is the faster kernel (1024 games 1.25 ms against 1.43, 2048 1.80 against 1.89);
+     * beyond, k_search_fused at four waves per SIMD is (4096: 2.99 against 3.43 at any occupancy of vis4: its
+     * barriers hold a block's waves in step and a quarter of them idle in the head phase, which costs more
+     * than the shared weight rows save once the SIMDs are full).  MZS_VIS4_OCC (measurement only) lifts this. */
+    return (n_games + 3) / 4 <= 2 * h->n_cus || std::getenv("MZS_VIS4_OCC") != nullptr;
+}
 struct SearchPlan {
     int kind;
     quad_kernel_t kernel;
@@ -923,7 +1070,9 @@ SearchPlan plan_search(const mzs_handle* h, int S, int n_games) {
     const mzs_dims& d = h->cfg.dims;
     const int A = d.n_actions, n_nodes = mzs_nodes_per_game(A, S);
     pl.kind = kPlanGeneric;
-    std::snprintf(pl.name, sizeof pl.name, d.model_kind == MZS_MODEL_VISION ? "k_search_fused<false,vision>" : "k_search_fused<false>");
+    std::snprintf(pl.name, sizeof pl.name,
+                  d.model_kind == MZS_MODEL_VISION ? (vis4_ok(h, n_games) ? "k_search_vis4" : "k_search_fused<false,vision>")
+                                                   : "k_search_fused<false>");
     if (h->cfg.engine != MZS_ENGINE_FUSED || mzs_max_draws(A, S) >= (1ll << 31)) return pl;
     static const bool no_occ2 = std::getenv("MZS_NO_OCC2") != nullptr; /* measurement knob: same results either way */
     if ((n_games + 15) / 16 > h->n_cus && !no_occ2) {
@@ -1112,9 +1261,10 @@ int mzs_create(const mzs_config* cfg, mzs_handle** out) {
     describe_model(d, &h->model, &sb);
     h->w_floats = sb.data.size();
     if (d.model_kind == MZS_MODEL_VISION) /* the Linear layers' quad store (mzs_vision.h) */
-        h->w_floats = vis_lin_total(d.hidden_dim, d.n_mid_layers, d.state_dim, d.n_actions);
+        h->w_floats = vis_lin_total(d.hidden_dim, d.n_mid_layers, d.state_dim, d.n_actions) +
+                      vis_mm_total(d.hidden_dim, d.n_mid_layers, d.state_dim, d.n_actions); /* + the MFMA store */
     h->n_nodes_max = mzs_nodes_per_game(d.n_actions, cfg->max_simulations);
-    h->lds = make_lds_layout(h->model, h->n_nodes_max, cfg->max_simulations, d.model_kind == MZS_MODEL_VISION);
+    h->lds = make_lds_layout(h->model, h->n_nodes_max, cfg->max_simulations, d.model_kind == MZS_MODEL_VISION ? 1 : 0);
     if (waves_per_block(h->lds) == 0) {
         delete h;
         return fail(MZS_E_ARG, "tree + activations of one game exceed 160 KiB of LDS");
@@ -1208,7 +1358,7 @@ int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats) {
          * head MLPs from a store of their own, laid out for 16-byte loads (mzs_vision.h, vis_lin_offsets) */
         HIP_TRY(hipMemcpy(h->blob_dev, B, n_floats * sizeof(float), hipMemcpyHostToDevice));
         /* the quad store of mzs_vision.h (vis_lin_offsets) */
-        std::vector<float> t(vis_lin_total(H, d.n_mid_layers, Sd, A), 0.0f);
+        std::vector<float> t(vis_lin_total(H, d.n_mid_layers, Sd, A) + vis_mm_total(H, d.n_mid_layers, Sd, A), 0.0f);
         const mzs_vision_offsets vo = mzs_vision_layout(&d);
         const auto quads = [&](size_t dst, size_t src, int n_out, int n_in) {
             const int Q = n_in / 4;
@@ -1228,6 +1378,17 @@ int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats) {
             quads(lw.in_w, fc->in_w, H, MZS_VIS_HIDDEN);
             if (d.n_mid_layers > 0) quads(lw.mid_w, fc->mid_w, H, H);
             quads(lw.out_w, fc->out_w, fc->n_out, H);
+            /* the same matrices for the matrix core (mzs_vision_mm.h): [Kpad / 4][NPAD][4], zero padded */
+            const auto mm = [&](size_t dst, size_t src, int n_out, int n_in) {
+                const size_t NP = vis_mm_r(n_out, 64);
+                for (int j = 0; j < n_out; ++j)
+                    for (int k = 0; k < n_in; ++k)
+                        t[dst + ((size_t)(k / 4) * NP + j) * 4 + k % 4] = B[src + (size_t)j * n_in + k];
+            };
+            const VisLin mw = vis_mm_offsets(hd, H, d.n_mid_layers, Sd, A);
+            mm(mw.in_w, fc->in_w, H, MZS_VIS_HIDDEN);
+            if (d.n_mid_layers > 0) mm(mw.mid_w, fc->mid_w, H, H);
+            mm(mw.out_w, fc->out_w, fc->n_out, H);
         }
         HIP_TRY(hipMemcpy(h->w_dev, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
         h->have_weights = true;
@@ -1312,7 +1473,35 @@ static int search_launch(mzs_handle* h, int32_t n_games, int32_t S, int32_t trai
             if (rc) return rc;
         }
         p.t_root_policy = h->root_policy_dev;
-        p.lds = make_lds_layout(h->model, p.n_nodes, S, true);
+        if (vis4_ok(h, n_games)) {
+            /* four games per block, the head MLPs on the matrix core (k_search_vis4): the per-wave slices, then
+             * the block's parameter cache and the head phase's buffers.  As many blocks per CU as the LDS seats
+             * (each block is one wave per SIMD), at most four, and no more than the batch can use: fewer waves
+             * per SIMD leave each of them more registers. */
+            const mzs_dims& d = h->cfg.dims;
+            p.lds = make_lds_layout(h->model, p.n_nodes, S, 2);
+            const size_t bytes = (size_t)4 * p.lds.bytes +
+                                 (kVisCache + vis_mm_lds_floats(d.hidden_dim, d.state_dim, d.n_actions)) * sizeof(float);
+            const int blocks = (n_games + 3) / 4;
+            int occ = (int)((size_t)kMaxLdsPerBlock / bytes);
+            occ = occ > 4 ? 4 : occ;
+            while (occ > 2 && blocks <= (occ - 1) * h->n_cus) --occ;
+            if (const char* ev = std::getenv("MZS_VIS4_OCC")) { /* measurement only (tools/bench_vision.py) */
+                const int want = std::atoi(ev);
+                if (want >= 2 && want <= occ) occ = want;
+                if (want == 1) occ = 0; /* 1: fall back to k_search_fused */
+            }
+            if (occ >= 2) {
+                auto kern = occ == 4 ? k_search_vis4<4> : (occ == 3 ? k_search_vis4<3> : k_search_vis4<2>);
+                if (bytes > 64 * 1024)
+                    HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+                hipLaunchKernelGGL(kern, dim3(blocks), dim3(256), bytes, st, p);
+                HIP_TRY(hipGetLastError());
+                return MZS_OK;
+            }
+        }
+        p.lds = make_lds_layout(h->model, p.n_nodes, S, 1);
         /* up to two waves per SIMD's worth of games: the build with 256 registers; more: four per SIMD */
         return n_games <= 8 * h->n_cus ? launch(k_search_fused<false, true, 2>, p, n_games, p.lds, st)
                                        : launch(k_search_fused<false, true, 4>, p, n_games, p.lds, st);

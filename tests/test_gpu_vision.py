@@ -54,19 +54,23 @@ def test_vision_inference_equals_oracle_and_reference(name):
     eng.close()
 
 
-@pytest.mark.parametrize("name,G,S", [("visA", 21, 30), ("visB", 9, 12)])
-def test_vision_search_equals_oracle(name, G, S):
+@pytest.mark.parametrize("engine", ["fused", "generic"])
+@pytest.mark.parametrize("name,G,S", [("visA", 21, 30), ("visB", 9, 12), ("visA", 4, 5), ("visB", 1, 7)])
+def test_vision_search_equals_oracle(name, G, S, engine):
     """Whole searches (Monte_carlo_tree_search.run on the vision networks) through mzs_search_streams:
     visit counts, root values, consumed draws and the hidden state of every expansion == the oracle's
-    search on the same images and streams, bit for bit.  One game per wavefront (k_search_fused)."""
-    from muzero_amd import rng
+    search on the same images and streams, bit for bit.  engine "fused": k_search_vis4 (four games per block,
+    the head MLPs on the matrix core; ragged game counts leave waves that replay the last game); "generic":
+    k_search_fused (one game per wavefront, lane-per-output Linear layers) — two implementations, one oracle."""
+    from muzero_amd import _lib, rng
     from oracle import mz_oracle as mzo
     d, blob = fixture_weights(name)
     obs = np.random.RandomState(7).uniform(0.0, 1.0, size=(G, 3, 98, 98)).astype(np.float32)
     seeds = np.arange(G, dtype=np.int64) + 321
-    eng = engine_for(d, G, S, discount=0.997)
+    eng = engine_for(d, G, S, discount=0.997,
+                     engine=_lib.ENGINE_FUSED if engine == "fused" else _lib.ENGINE_FUSED_GENERIC)
     eng.set_weights(blob)
-    assert "fused" in eng.search_kernel_name(S)
+    assert eng.search_kernel_name(S) == ("k_search_vis4" if engine == "fused" else "k_search_fused<false,vision>")
     eng.search_streams(obs, seeds, S, True)
     out, tree = eng.results_host(), eng.tree_host()
     dirichlet, noise = eng.fill_streams(seeds, S, True)
@@ -77,17 +81,18 @@ def test_vision_search_equals_oracle(name, G, S):
     assert np.array_equal(out["consumed"], ref["consumed"])
     assert np.array_equal(bits(tree["hidden"]), bits(ref["hidden"]))
     assert out["visits"].sum() == G * S and np.all(tree["status"] == 0)
-    assert len({tuple(v) for v in out["visits"]}) > 1          # the searches are not all alike
+    assert G == 1 or len({tuple(v) for v in out["visits"]}) > 1          # the searches are not all alike
     eng.close()
 
 
-def test_vision_search_many_games_equals_oracle():
-    """More games than two wavefronts per SIMD hold (8 x CUs): search_launch switches to the build of the
-    simulation kernel compiled for four waves per SIMD (128 registers, 32-row Linear batches).  Its
-    results on 8 x CUs + 256 games — copies of twelve distinct games — equal the oracle's for those
-    twelve, bit for bit, in every copy."""
+@pytest.mark.parametrize("engine", ["fused", "generic"])
+def test_vision_search_many_games_equals_oracle(engine):
+    """More games than two blocks of k_search_vis4 per CU hold (8 x CUs + 256): search_launch switches to the
+    build of k_search_fused compiled for four waves per SIMD (128 registers, 32-row Linear batches), under
+    either engine.  Results — copies of twelve distinct games — equal the oracle's for those twelve, bit for
+    bit, in every copy."""
     import torch
-    from muzero_amd import rng  # noqa: F401
+    from muzero_amd import _lib, rng  # noqa: F401
     from oracle import mz_oracle as mzo
     name, K, S = "visA", 12, 12
     d, blob = fixture_weights(name)
@@ -95,7 +100,8 @@ def test_vision_search_many_games_equals_oracle():
     obs_k = np.random.RandomState(11).uniform(0.0, 1.0, size=(K, 3, 98, 98)).astype(np.float32)
     seeds_k = np.arange(K, dtype=np.int64) + 77
     idx = np.arange(G) % K
-    eng = engine_for(d, G, S, discount=0.997)
+    eng = engine_for(d, G, S, discount=0.997,
+                     engine=_lib.ENGINE_FUSED if engine == "fused" else _lib.ENGINE_FUSED_GENERIC)
     eng.set_weights(blob)
     eng.search_streams(torch.as_tensor(obs_k).cuda()[torch.as_tensor(idx).cuda()], seeds_k[idx], S, True)
     out, tree = eng.results_host(), eng.tree_host()
@@ -107,6 +113,34 @@ def test_vision_search_many_games_equals_oracle():
     assert np.array_equal(out["consumed"], ref["consumed"][idx])
     assert np.array_equal(bits(tree["hidden"]), bits(ref["hidden"][idx]))
     assert np.all(tree["status"] == 0)
+    eng.close()
+
+
+def test_vision_search_two_blocks_per_cu_equals_oracle():
+    """k_search_vis4 with two resident blocks on every CU (8 x CUs games, the largest batch it is dispatched for):
+    copies of twelve distinct games, each == the oracle's, bit for bit, over two launches in a row."""
+    import torch
+    from oracle import mz_oracle as mzo
+    name, K, S = "visB", 12, 10
+    d, blob = fixture_weights(name)
+    G = 8 * torch.cuda.get_device_properties(0).multi_processor_count
+    obs_k = np.random.RandomState(13).uniform(0.0, 1.0, size=(K, 3, 98, 98)).astype(np.float32)
+    seeds_k = np.arange(K, dtype=np.int64) + 177
+    idx = np.arange(G) % K
+    eng = engine_for(d, G, S, discount=0.997)
+    assert eng.search_kernel_name(S) == "k_search_vis4"
+    dirichlet, noise = eng.fill_streams(seeds_k, S, True)
+    ref = mzo.search(d, blob, S, 0.997, 0.25, eng.pbc, obs=obs_k, dirichlet=dirichlet.cpu().numpy(),
+                     noise=noise.cpu().numpy(), train=True, want=("visits", "root_value", "consumed", "hidden"))
+    eng.set_weights(blob)
+    for _ in range(2):
+        eng.search_streams(torch.as_tensor(obs_k).cuda()[torch.as_tensor(idx).cuda()], seeds_k[idx], S, True)
+        out, tree = eng.results_host(), eng.tree_host()
+        assert np.array_equal(out["visits"], ref["visits"][idx])
+        assert np.array_equal(bits(out["root_value"]), bits(ref["root_value"][idx]))
+        assert np.array_equal(out["consumed"], ref["consumed"][idx])
+        assert np.array_equal(bits(tree["hidden"]), bits(ref["hidden"][idx]))
+        assert np.all(tree["status"] == 0)
     eng.close()
 
 
