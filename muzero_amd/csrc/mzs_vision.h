@@ -395,8 +395,8 @@ __device__ __forceinline__ void vis_linear(const float* __restrict__ W, const fl
 
 /* 1x1 convolution (+bias) of x [Ci][49] -> flatten -> Linear, relu, (Linear, relu) x L, Linear: logits.
  * cw: the cached parameters (conv_w, conv_b are blob offsets into them) */
-template <int NB>
-__device__ __forceinline__ void vis_head_mlp(const Model& m, const float* __restrict__ blob, const float* cw,
+template <int NB, class WP>
+__device__ __forceinline__ void vis_head_mlp(const Model& m, const float* __restrict__ blob, WP cw,
                                              size_t conv_w, size_t conv_b, int Ci, size_t fc_base, int head, int n_out,
                                              const float* x, float* logits, float* t1, float* t2, int lane) {
     constexpr int CM = kVisC + 1;
@@ -488,7 +488,10 @@ __device__ __forceinline__ float vis_dynamics(const Model& m, const WaveLds& L, 
     const float pv = (float)(action + 1) / (float)m.A;
     for (int i = lane; i < kVisPix; i += kWave) L.xh[kVisHidden + i] = pv;
     wave_sync();
-    const float* cw = L.vc;
+    /* the convolutions' and batchnorms' parameters straight from the blob through the constant address space:
+     * uniform addresses, so scalar loads, and the weights reach the fma chains as scalar operands (the
+     * simulations of a search; the representation keeps its LDS cache) */
+    const VisConstPtr cw = (VisConstPtr)m.blob;
     vis_conv3_bn<kVisC + 1, kVisC>(cw, o.d_conv, o.d_bn, L.xh, x, lane);
     for (int l = 0; l < m.L; ++l) vis_res_block(cw, o.d_res.conv_a, kVisC, x, MZS_VIS_S4, t1, t2, lane);
     vis_head_mlp<NB>(m, blob, cw, o.d_conv_rew, o.d_conv_rew_b, kVisC + 1, o.d_fc.in_w, 0, m.Sd, L.xh, logits, t1, t2, lane);
@@ -510,13 +513,12 @@ __device__ __forceinline__ float vis_prediction(const Model& m, const WaveLds& L
     float *x = L.ob, *t1 = L.xa, *t2 = L.xb, *logits = L.ob + 256;
     for (int i = lane; i < kVisHidden; i += kWave) x[i] = L.xh[i];
     wave_sync();
-    const float* cw = L.vc;
-    const size_t dl = vis_cache_delta(o);
-    for (int l = 0; l < m.L; ++l) vis_res_block(cw, o.p_res.conv_a - dl, kVisC, x, MZS_VIS_S4, t1, t2, lane);
+    const VisConstPtr cw = (VisConstPtr)m.blob;
+    for (int l = 0; l < m.L; ++l) vis_res_block(cw, o.p_res.conv_a, kVisC, x, MZS_VIS_S4, t1, t2, lane);
     float value = 0.0f;
 #pragma nounroll
     for (int hd = 0; hd < 2; ++hd) { /* value head, then policy head: one copy of the head's code */
-        const size_t cv = (hd ? o.p_conv_pol : o.p_conv_val) - dl, cb = (hd ? o.p_conv_pol_b : o.p_conv_val_b) - dl;
+        const size_t cv = hd ? o.p_conv_pol : o.p_conv_val, cb = hd ? o.p_conv_pol_b : o.p_conv_val_b;
         vis_head_mlp<NB>(m, blob, cw, cv, cb, kVisC, hd ? o.p_p.in_w : o.p_v.in_w, 1 + hd, hd ? m.A : m.Sd, x, logits, t1, t2, lane);
         if (hd == 0) {
             value = seg_support_scalar(logits, m.Sd, lane);
