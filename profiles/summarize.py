@@ -23,6 +23,19 @@ def main():
     lines += ["## kernel-trace --stats", "", "| kernel | calls | total ns | avg ns | min ns | max ns | % |", "|---|---|---|---|---|---|---|"]
     for r in st:
         lines.append(f"| {r['Name'][:90]} | {r['Calls']} | {r['TotalDurationNs']} | {float(r['AverageNs']):.0f} | {r['MinNs']} | {r['MaxNs']} | {r['Percentage']} |")
+    # working launches of the search kernels: a run through mzs_search_streams adds empty redo launches of the
+    # same kernel (a few microseconds each), which the --stats average above mixes in
+    tr = rows(os.path.join(src, "trace", "**", "*kernel_trace.csv"))
+    per = {}
+    for r in tr:
+        if "k_search" in r["Kernel_Name"] or "k_inference" in r["Kernel_Name"]:
+            per.setdefault(r["Kernel_Name"][:90], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    if per:
+        lines += ["", "## working launches (duration > 25 % of the kernel's longest)", "",
+                  "| kernel | launches | working | avg ns | median ns | min ns | max ns |", "|---|---|---|---|---|---|---|"]
+        for k, v in per.items():
+            w = sorted(t for t in v if t > 0.25 * max(v))
+            lines.append(f"| {k} | {len(v)} | {len(w)} | {sum(w) / len(w):.0f} | {w[len(w) // 2]} | {w[0]} | {w[-1]} |")
     for name in ("fetch", "write", "sq", "mfma"):
         pm = rows(os.path.join(src, f"pmc_{name}", "**", "*counter_collection.csv"))
         agg = {}
