@@ -31,10 +31,13 @@ def main():
         if "k_search" in r["Kernel_Name"] or "k_inference" in r["Kernel_Name"]:
             per.setdefault(r["Kernel_Name"][:90], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     if per:
-        lines += ["", "## working launches (duration > 25 % of the kernel's longest)", "",
+        lines += ["", "## working launches (duration > half the median of the launches above 20 us; the first launch of a "
+                  "process, which loads the code object, excluded when it is an outlier)", "",
                   "| kernel | launches | working | avg ns | median ns | min ns | max ns |", "|---|---|---|---|---|---|---|"]
         for k, v in per.items():
-            w = sorted(t for t in v if t > 0.25 * max(v))
+            big = sorted(t for t in v if t > 20000) or sorted(v)
+            med = big[len(big) // 2]
+            w = sorted(t for t in v if 0.5 * med < t < 3 * med)
             lines.append(f"| {k} | {len(v)} | {len(w)} | {sum(w) / len(w):.0f} | {w[len(w) // 2]} | {w[0]} | {w[-1]} |")
     for name in ("fetch", "write", "sq", "mfma"):
         pm = rows(os.path.join(src, f"pmc_{name}", "**", "*counter_collection.csv"))
