@@ -44,7 +44,7 @@ typedef struct mzs_dims {
     int32_t n_mid_layers; /* L: how many times the tied mid layer is applied (MLP);
                              num_layers of every nn.LSTM (LSTM model, 1..MZS_LSTM_MAX_LAYERS) */
     int32_t model_kind;   /* MZS_MODEL_MLP (0, 'mlp_model'), MZS_MODEL_LSTM ('lstm_model') or
-                             MZS_MODEL_VISION ('vision_model', inference entry points only)     */
+                             MZS_MODEL_VISION ('vision_model')                                    */
     int32_t precision;    /* MZS_PRECISION_F32 (0), MZS_PRECISION_BF16 or MZS_PRECISION_BF16X3:
                              Muzero(type_format=...), muzero_model.py:194-204.  bf16 = weights and layer
                              inputs rounded to bfloat16, fp32 accumulation and epilogues; bf16x3 = both

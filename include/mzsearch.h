@@ -228,6 +228,27 @@ int mzs_train_grad_static(mzs_handle* h, int32_t batch, int32_t unroll_steps, co
                           const float* is_ratio_dev, float inv_global_batch, float* grad_dev, float* loss_dev,
                           float* priority_dev, void* stream);
 
+/* 'vision_model' (mzs_dims.model_kind = MZS_MODEL_VISION; neural_network_vision_model.py in training mode):
+ * the same three calls — mzs_train_create, mzs_train_grad (obs_dev [B][3][98][98]; the action plane of step k is
+ * (argmax(actions[k][b]) + 1) / A, muzero_model.py:505-516), mzs_train_apply — with two additions:
+ *   BatchNorm2d runs on batch statistics (of this rank's shard, as torch.nn.DataParallel's replicas do,
+ *   muzero_model.py:333-340) and every application moves the running statistics (momentum 0.1); the K-th
+ *   dynamics / prediction calls, whose outputs evaluate_loss drops, still run for that.  The blob slots of the
+ *   running statistics come back in grad_dev holding (new - old) x batch x inv_global_batch: ranks SUM them
+ *   with the gradient and mzs_train_apply ADDS the sum to the blob instead of optimising it.
+ *   Dropout2d(p = 0.5) zeroes whole (sample, channel) maps, three times per residual block.  torch draws the
+ *   masks from its generator; here they come from a counter-based generator keyed by (seed, call number), or
+ *   — for parity tests against recorded reference runs — from the caller: */
+
+/* bytes of masks one mzs_train_grad on `batch` samples consumes: one per (Dropout2d call, sample, channel),
+ * calls in the reference's forward order (representation, prediction, K x (dynamics, prediction)) */
+int mzs_train_dropout_count(mzs_handle* h, int32_t batch, int64_t* n_out);
+
+/* masks_dev != NULL: the NEXT mzs_train_grad reads its masks (1 = kept, scaled by 2; 0 = dropped) from
+ * masks_dev[0 .. n_masks), which must equal mzs_train_dropout_count and stay valid until that call's kernels
+ * have run; later calls draw their own again.  masks_dev == NULL: restart the generator at `seed`. */
+int mzs_train_set_dropout(mzs_handle* h, const unsigned char* masks_dev, int64_t n_masks, uint64_t seed);
+
 /* The criteria of the value and reward terms of evaluate_loss, i.e. the reference's loss_type
  * (init_criterion_and_optimizer, muzero_model.py:350-403; Loss_function, neural_network_mlp_model.py:
  * 236-262, always on softmax(logits) + 1e-9): 'general' = CE / CE (the default), 'general_kkc' =

@@ -87,6 +87,8 @@ _SIGNATURES = {
     "mzs_train_set_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32]),
     "mzs_train_set_momentum": (C.c_int, [C.c_void_p, C.c_double]),
     "mzs_train_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_double, C.c_void_p]),
+    "mzs_train_dropout_count": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_int64)]),
+    "mzs_train_set_dropout": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_uint64]),
     "mzs_get_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "mzs_arena_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "mzs_arena_destroy": (None, [C.c_void_p]),

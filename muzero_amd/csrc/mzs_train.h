@@ -21,6 +21,7 @@
 #define MZS_TRAIN_H
 
 #include "mzs_device.h"
+#include "mzs_train_loss.h"
 
 namespace mzs {
 
@@ -131,9 +132,6 @@ __device__ __forceinline__ void train_back_input(const float* __restrict__ W, in
     wave_sync();
 }
 
-/* order-free sum over the wave of one value per lane */
-__device__ __forceinline__ float train_sum(float v) { return wave_tree_sum(v); }
-
 struct ScaleRec {
     int imin, imax;
     float sc;
@@ -167,71 +165,6 @@ __device__ __forceinline__ void train_scale_bwd(const float* g, const float* h, 
     if (lane == r.imax) o += dsc;
     if (valid) gz[lane] = o;
     wave_sync();
-}
-
-/* transform_with_support (muzero_model.py:536-563): the one (index, weight) pair it scatters */
-__device__ __forceinline__ void train_support_target(float x, int S, int* idx, float* weight) {
-    const int sd = S / 2, rem = S & 1;
-    const float ax = fabsf(x);
-    const float sg0 = x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f);
-    float t = sg0 * (__builtin_sqrtf(ax + 1.0f) - 1.0f) + 0.001f * x;
-    t = fmaxf(t, (float)-sd);
-    t = fminf(t, (float)(sd + rem));
-    const float sg = t > 0.0f ? 1.0f : (t < 0.0f ? -1.0f : 0.0f);
-    int i = (int)(floorf(t) + (float)sd + 1.0f);
-    i = i < -(S - 1) ? -(S - 1) : (i > S - 1 ? S - 1 : i);
-    *idx = i;
-    *weight = (ceilf(t) - t) * sg;
-}
-
-/* One loss term of evaluate_loss (muzero_model.py:650-700): criterion `mode` (MZS_LOSS_*, the
- * Loss_function methods of neural_network_mlp_model.py:236-262) of q = softmax(z) + 1e-9 against the
- * target p (this lane's entry); delta = upstream * dloss/dz to dz[0..n).  With c = dloss/dq:
- *   CE  -sum p log q, c = -p / q          KL  sum p' (log p' - log q), p' = p + 1e-9, c = -p' / q
- *   MSE mean (p - q)^2, c = -2 (p - q) / n          ZERO 0, c = 0
- * and dloss/dz = s (c - sum c s).  Returns the loss (uniform); *softmax_out = this lane's softmax
- * probability. */
-/* criterion of the policy term: always the cross-entropy, against p + 1e-9 when the loss type is
- * 'general_kkc' (label = ["zero_clamp_transform"], muzero_model.py:373-375) — the one loss type whose
- * value criterion is the KL divergence, which is how the kernels recognise it */
-constexpr int kLossCeClamped = 100;
-__device__ __forceinline__ int train_policy_mode(int loss_value) {
-    return loss_value == MZS_LOSS_KL ? kLossCeClamped : MZS_LOSS_CE;
-}
-
-__device__ __forceinline__ float train_ce(const float* z, int n, float p, float upstream, float* dz,
-                                          float* softmax_out, int lane, int mode = MZS_LOSS_CE) {
-    const bool valid = lane < n;
-    const float zv = valid ? z[lane] : 0.0f;
-    const float m = wave_max(valid ? zv : -__builtin_inff());
-    const float e = valid ? expf(zv - m) : 0.0f;
-    const float Z = train_sum(e);
-    const float s = e / Z;
-    const float q = s + 1e-9f;
-    const float pv = valid ? p : 0.0f;
-    float c, term;
-    if (mode == MZS_LOSS_CE || mode == kLossCeClamped) {
-        const float pc = mode == kLossCeClamped ? pv + 1e-9f : pv;
-        c = -pc / q;
-        term = -pc * logf(q);
-    } else if (mode == MZS_LOSS_KL) {
-        const float pp = pv + 1e-9f;
-        c = -pp / q;
-        term = pp * (logf(pp) - logf(q));
-    } else if (mode == MZS_LOSS_MSE) {
-        const float d = pv - q;
-        c = -2.0f * d / (float)n;
-        term = d * d / (float)n;
-    } else {
-        c = 0.0f;
-        term = 0.0f;
-    }
-    const float loss = train_sum(valid ? term : 0.0f);
-    const float dot = train_sum(valid ? c * s : 0.0f);
-    if (valid) dz[lane] = upstream * s * (c - dot);
-    *softmax_out = s;
-    wave_sync();
-    return loss;
 }
 
 /* backward through one MLP trunk: gT holds dL/d(last trunk activation) on entry */
@@ -463,7 +396,10 @@ struct ApplyParams {
     float* blob;
     float* store;
     float* store16;         /* MZS_PRECISION_BF16: the search's copy (weights rounded to bfloat16), else null */
-    const int* store_index; /* blob element -> offset in the device weight store; bit 30: a bias */
+    const int* store_index; /* blob element -> offset in the device weight store; bit 30: a bias; null: no store
+                               (vision_model: k_vis_store_refresh rebuilds its Linear stores) */
+    const unsigned char* is_stat; /* vision_model: 1 = a BatchNorm running statistic, whose "gradient" slot holds
+                                     the (rank-summed) change of this step: added, not optimised; else null */
     float* m;
     float* v;
     const float* grad;
@@ -479,6 +415,10 @@ __global__ void __launch_bounds__(256) k_train_apply(const ApplyParams p) {
     if (i >= p.n) return;
     const float g = p.grad[i];
     float w = p.blob[i];
+    if (p.is_stat && p.is_stat[i]) {
+        p.blob[i] = w + g;
+        return;
+    }
     if (p.optimizer == 0) {
         float m = p.m[i], v = p.v[i];
         m = m + (g - m) * p.one_minus_momentum;
@@ -493,10 +433,19 @@ __global__ void __launch_bounds__(256) k_train_apply(const ApplyParams p) {
         w = w - p.lr * buf;
     }
     p.blob[i] = w;
+    if (!p.store_index) return;
     const int si = p.store_index[i], so = si & 0x3fffffff;
     if (si == -1) return; /* not in the store: a search never reads it (LSTM W_hh, forget-gate rows) */
     p.store[so] = w;
     if (p.store16) p.store16[so] = ((si >> 30) & 1) ? w : mzs_bf16_round(w);
+}
+
+/* vision_model: the Linear layers' stores (quads for mzs_vision.h, [K/4][N_pad][4] for mzs_vision_mm.h) are
+ * permutations of blob elements with zero padding: src[i] = blob index or -1 */
+__global__ void __launch_bounds__(256) k_vis_store_refresh(float* __restrict__ store, const int* __restrict__ src,
+                                                           const float* __restrict__ blob, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) store[i] = src[i] >= 0 ? blob[src[i]] : 0.0f;
 }
 
 }  // namespace mzs

@@ -32,6 +32,7 @@
 #include "mzs_train_lstm.h"
 #include "mzs_selfplay.h"
 #include "mzs_replay.h"
+#include "mzs_vision_train.h"
 
 using namespace mzs;
 
@@ -651,6 +652,11 @@ struct mzs_handle {
     float* adam_v_dev = nullptr;
     double* wgrad_partial_dev = nullptr;
     LstmTrainParams lstm_train;    /* 'lstm_model': tape layout and descriptor tables of mzs_train_create */
+    VisTrain* vis_train = nullptr; /* 'vision_model': mzs_vision_train.hip */
+    int* vis_store_src_dev = nullptr; /* vision: element of the Linear stores (w_dev) -> blob index, -1 = padding */
+    const unsigned char* dropout_masks = nullptr; /* mzs_train_set_dropout: injected masks for the NEXT gradient call */
+    int64_t dropout_n = 0;
+    uint64_t dropout_seed = 0x5DEECE66Dull, train_calls = 0;
     int loss_value = MZS_LOSS_CE, loss_reward = MZS_LOSS_CE; /* mzs_train_set_loss */
     double momentum = 0.9;                                   /* mzs_train_set_momentum */
     size_t w_floats = 0;
@@ -1336,6 +1342,7 @@ void mzs_destroy(mzs_handle* h) {
     if (!h) return;
     (void)hipSetDevice(h->cfg.device);
     for (void* p : h->allocs) (void)hipFree(p);
+    vis_train_destroy(h->vis_train);
     delete h;
 }
 
@@ -1357,9 +1364,20 @@ int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats) {
         /* convolutions, batchnorms and biases are read from the blob in place; the Linear layers of the three
          * head MLPs from a store of their own, laid out for 16-byte loads (mzs_vision.h, vis_lin_offsets) */
         HIP_TRY(hipMemcpy(h->blob_dev, B, n_floats * sizeof(float), hipMemcpyHostToDevice));
-        /* the quad store of mzs_vision.h (vis_lin_offsets) */
-        std::vector<float> t(vis_lin_total(H, d.n_mid_layers, Sd, A) + vis_mm_total(H, d.n_mid_layers, Sd, A), 0.0f);
+        const size_t n_store = vis_lin_total(H, d.n_mid_layers, Sd, A) + vis_mm_total(H, d.n_mid_layers, Sd, A);
         const mzs_vision_offsets vo = mzs_vision_layout(&d);
+        /* pass 0 fills the stores with the weights; pass 1 runs the same permutation over the blob INDICES
+         * (exact in a float below 2^24), which is what refreshes the stores after a training step */
+        std::vector<float> ids;
+        if (!h->vis_store_src_dev) {
+            if (n_floats >= (size_t)1 << 24) return fail(MZS_E_ARG, "vision blob too large for the store index");
+            ids.resize(n_floats);
+            for (size_t i = 0; i < n_floats; ++i) ids[i] = (float)(i + 1);
+        }
+        for (int pass = 0; pass < (ids.empty() ? 1 : 2); ++pass) {
+        const float* B = pass == 0 ? host.data() : ids.data();
+        /* the quad store of mzs_vision.h (vis_lin_offsets) */
+        std::vector<float> t(n_store, 0.0f);
         const auto quads = [&](size_t dst, size_t src, int n_out, int n_in) {
             const int Q = n_in / 4;
             for (int j = 0; j < n_out; ++j)
@@ -1390,7 +1408,16 @@ int mzs_set_weights(mzs_handle* h, const float* blob, size_t n_floats) {
             if (d.n_mid_layers > 0) mm(mw.mid_w, fc->mid_w, H, H);
             mm(mw.out_w, fc->out_w, fc->n_out, H);
         }
-        HIP_TRY(hipMemcpy(h->w_dev, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+        if (pass == 0) {
+            HIP_TRY(hipMemcpy(h->w_dev, t.data(), t.size() * sizeof(float), hipMemcpyHostToDevice));
+        } else {
+            std::vector<int> src(n_store);
+            for (size_t i = 0; i < n_store; ++i) src[i] = (int)t[i] - 1;
+            int rc = dev_alloc(h, &h->vis_store_src_dev, n_store);
+            if (rc) return rc;
+            HIP_TRY(hipMemcpy(h->vis_store_src_dev, src.data(), n_store * sizeof(int), hipMemcpyHostToDevice));
+        }
+        }
         h->have_weights = true;
         return MZS_OK;
     }
@@ -2006,10 +2033,19 @@ int mzs_train_create(mzs_handle* h, int32_t max_batch, int32_t unroll_steps) {
     const mzs_dims& d = h->cfg.dims;
     if (d.state_dim > 64 || d.n_actions > 64)
         return fail(MZS_E_ARG, "training kernels hold one logit per lane: state_dim and n_actions <= 64");
-    if (h->tape_dev) return fail(MZS_E_STATE, "mzs_train_create was already called on this handle");
-    if (d.model_kind == MZS_MODEL_VISION)
-        return fail(MZS_E_ARG, "training kernels exist for mlp_model and lstm_model (vision_model: inference and search)");
+    if (h->tape_dev || h->vis_train) return fail(MZS_E_STATE, "mzs_train_create was already called on this handle");
     HIP_TRY(hipSetDevice(h->cfg.device));
+    if (d.model_kind == MZS_MODEL_VISION) {
+        std::string err;
+        const size_t nb = mzs_blob_total(&d);
+        int rc = vis_train_create(&h->vis_train, d, max_batch, unroll_steps, h->cfg.device, &err);
+        if (rc) return fail(rc, err);
+        if ((rc = dev_alloc(h, &h->adam_m_dev, nb)) || (rc = dev_alloc(h, &h->adam_v_dev, nb))) return rc;
+        h->train_batch = max_batch;
+        h->train_K = unroll_steps;
+        h->train_step = 0;
+        return MZS_OK;
+    }
     if (d.model_kind == MZS_MODEL_LSTM) return lstm_train_create(h, max_batch, unroll_steps);
     const TapeLayout t = make_tape_layout(h->model, unroll_steps);
     if ((size_t)t.total * sizeof(float) > (size_t)kMaxLdsPerBlock)
@@ -2080,13 +2116,29 @@ int mzs_train_grad(mzs_handle* h, int32_t batch, const float* obs_dev, const flo
                    const float* target_policy_dev, const float* is_ratio_dev, float inv_global_batch,
                    float* grad_dev, float* loss_dev, float* priority_dev, void* stream) {
     if (!h) return fail(MZS_E_ARG, "null handle");
-    if (!h->tape_dev) return fail(MZS_E_STATE, "mzs_train_create has not been called");
+    if (!h->tape_dev && !h->vis_train) return fail(MZS_E_STATE, "mzs_train_create has not been called");
     if (!h->have_weights) return fail(MZS_E_STATE, "mzs_set_weights has not been called");
     if (batch < 1 || batch > h->train_batch) return fail(MZS_E_ARG, "batch exceeds max_batch of mzs_train_create");
     if (!obs_dev || !actions_dev || !target_value_dev || !target_reward_dev || !target_policy_dev ||
         !grad_dev || !loss_dev || !priority_dev)
         return fail(MZS_E_ARG, "null buffer");
     HIP_TRY(hipSetDevice(h->cfg.device));
+    if (h->vis_train) {
+        const unsigned char* masks = h->dropout_masks;
+        if (masks && h->dropout_n != vis_train_mask_count(h->vis_train, batch)) {
+            char msg[160];
+            std::snprintf(msg, sizeof msg, "mzs_train_set_dropout gave %lld mask bytes, a step on %d samples consumes %lld",
+                          (long long)h->dropout_n, batch, (long long)vis_train_mask_count(h->vis_train, batch));
+            return fail(MZS_E_ARG, msg);
+        }
+        h->dropout_masks = nullptr; /* injected masks serve one call */
+        std::string err;
+        const int rc = vis_train_grad(h->vis_train, h->blob_dev, batch, obs_dev, actions_dev, target_value_dev,
+                                      target_reward_dev, target_policy_dev, is_ratio_dev, inv_global_batch,
+                                      h->loss_value, h->loss_reward, masks, h->dropout_seed, h->train_calls++, grad_dev,
+                                      loss_dev, priority_dev, static_cast<hipStream_t>(stream), &err);
+        return rc ? fail(rc, err) : MZS_OK;
+    }
     if (h->cfg.dims.model_kind == MZS_MODEL_LSTM)
         return lstm_train_grad_launch(h, batch, obs_dev, actions_dev, target_value_dev, target_reward_dev,
                                       target_policy_dev, is_ratio_dev, inv_global_batch, grad_dev, loss_dev,
@@ -2167,7 +2219,7 @@ int mzs_train_set_momentum(mzs_handle* h, double momentum) {
 
 int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, double lr, void* stream) {
     if (!h || !grad_dev) return fail(MZS_E_ARG, "null argument");
-    if (!h->tape_dev) return fail(MZS_E_STATE, "mzs_train_create has not been called");
+    if (!h->tape_dev && !h->vis_train) return fail(MZS_E_STATE, "mzs_train_create has not been called");
     if (!h->have_weights) return fail(MZS_E_STATE, "mzs_set_weights has not been called");
     if (optimizer != MZS_OPT_ADAM && optimizer != MZS_OPT_SGD) return fail(MZS_E_ARG, "unknown optimizer");
     HIP_TRY(hipSetDevice(h->cfg.device));
@@ -2176,7 +2228,8 @@ int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, dou
     p.blob = h->blob_dev;
     p.store = h->w_dev;
     p.store16 = h->w_search_dev != h->w_dev ? h->w_search_dev : nullptr;
-    p.store_index = h->store_index_dev;
+    p.store_index = h->vis_train ? nullptr : h->store_index_dev;
+    p.is_stat = h->vis_train ? vis_train_stat_flags(h->vis_train) : nullptr;
     p.m = h->adam_m_dev;
     p.v = h->adam_v_dev;
     p.grad = grad_dev;
@@ -2191,7 +2244,33 @@ int mzs_train_apply(mzs_handle* h, const float* grad_dev, int32_t optimizer, dou
     p.lr = (float)lr;
     hipLaunchKernelGGL(k_train_apply, dim3((p.n + 255) / 256), dim3(256), 0,
                        static_cast<hipStream_t>(stream), p);
+    if (h->vis_train) { /* the Linear layers' stores of the search kernels (mzs_vision.h, mzs_vision_mm.h) */
+        const mzs_dims& d = h->cfg.dims;
+        const int n_store = (int)(vis_lin_total(d.hidden_dim, d.n_mid_layers, d.state_dim, d.n_actions) +
+                                  vis_mm_total(d.hidden_dim, d.n_mid_layers, d.state_dim, d.n_actions));
+        hipLaunchKernelGGL(k_vis_store_refresh, dim3((n_store + 255) / 256), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), h->w_dev, (const int*)h->vis_store_src_dev,
+                           (const float*)h->blob_dev, n_store);
+    }
     HIP_TRY(hipGetLastError());
+    return MZS_OK;
+}
+
+int mzs_train_dropout_count(mzs_handle* h, int32_t batch, int64_t* n_out) {
+    if (!h || !n_out) return fail(MZS_E_ARG, "null argument");
+    if (!h->vis_train) return fail(MZS_E_STATE, "mzs_train_dropout_count: vision_model after mzs_train_create only");
+    if (batch < 1 || batch > h->train_batch) return fail(MZS_E_ARG, "batch exceeds max_batch of mzs_train_create");
+    *n_out = vis_train_mask_count(h->vis_train, batch);
+    return MZS_OK;
+}
+
+int mzs_train_set_dropout(mzs_handle* h, const unsigned char* masks_dev, int64_t n_masks, uint64_t seed) {
+    if (!h) return fail(MZS_E_ARG, "null handle");
+    if (!h->vis_train) return fail(MZS_E_STATE, "mzs_train_set_dropout: vision_model after mzs_train_create only");
+    if (masks_dev && n_masks < 1) return fail(MZS_E_ARG, "mask count");
+    h->dropout_masks = masks_dev;
+    h->dropout_n = masks_dev ? n_masks : 0;
+    if (!masks_dev) h->dropout_seed = seed, h->train_calls = 0;
     return MZS_OK;
 }
 

@@ -411,17 +411,19 @@ class Muzero:
         With torch.distributed initialised each rank passes its shard of the batch.
         'lstm_model': every head's nn.LSTM reads the (B, H) batch as ONE sequence of length B
         (neural_network_lstm_model.py:35), and so do the kernels: the order of the samples matters,
-        and a rank's shard is a sequence of its own."""
+        and a rank's shard is a sequence of its own.
+        'vision_model': training mode as in the reference — BatchNorm2d on the batch statistics of this
+        rank's shard (running statistics move), Dropout2d masks from a device generator
+        (Trainer.set_dropout seeds it, or injects recorded masks)."""
         from . import train as tr
-        if self.model_structure == "vision_model":
-            raise NotImplementedError("train(): kernels exist for 'mlp_model' and 'lstm_model'; the vision model "
-                                      "runs inference and search (its training mode draws Dropout2d masks from "
-                                      "torch's generator and updates BatchNorm statistics: not built)")
         if self.loss_type not in tr.LOSS_TYPES:
             raise NotImplementedError(f"loss_type={self.loss_type!r}: the reference knows {sorted(tr.LOSS_TYPES)} "
                                       "(muzero_model.py:350-403)")
+        obs_floats = 3 * VISION_SIDE * VISION_SIDE if self.is_RGB else self.observation_dimension
         obs, actions, tv, trw, tp, ratio, game_pos = tr.reshape_batch(
-            batch, self.observation_dimension, self.action_dimension, self.k_hypothetical_steps)
+            batch, obs_floats, self.action_dimension, self.k_hypothetical_steps)
+        if self.is_RGB:       # (1, 3, 98, 98) tensors as game.py's transform makes them (:66-69)
+            obs = obs.reshape(-1, 3, VISION_SIDE, VISION_SIDE)
         B = obs.shape[0]
         if self._trainer is not None and self._trainer.max_batch < B:
             # refuse BEFORE touching any state: a retry must not succeed on a fresh optimizer

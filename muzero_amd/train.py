@@ -1,4 +1,4 @@
-"""Training step of the MLP MuZero model on the MI355X: host side of `Muzero.train`
+"""Training step of the MuZero models (mlp_model, lstm_model, vision_model) on the MI355X: host side of `Muzero.train`
 (/root/reference muzero_model.py:791-811).
 
 Host work (this file): reshape_batch (muzero_model.py:440-472), the learning-rate schedulers
@@ -170,6 +170,24 @@ class Trainer:
         self._sync_pending = not all_have
         if all_have:
             self.eng.set_weights(shard.broadcast_blob(self.weights(), dev))
+
+    def dropout_count(self, batch):
+        """vision_model: mask bytes one step on `batch` samples consumes (mzs_train_dropout_count)"""
+        n = C.c_int64(0)
+        _lib.check(self.lib.mzs_train_dropout_count(self.eng.h, int(batch), C.byref(n)), "mzs_train_dropout_count")
+        return int(n.value)
+
+    def set_dropout(self, masks=None, seed=0):
+        """vision_model: inject the Dropout2d masks of the NEXT step (uint8, one per (call, sample, channel) in the
+        reference's forward order — what tests/golden/make_vision_train_fixtures.py records), or with
+        masks=None restart the device generator at `seed`."""
+        if masks is None:
+            self._masks = None
+            _lib.check(self.lib.mzs_train_set_dropout(self.eng.h, None, 0, C.c_uint64(int(seed))), "mzs_train_set_dropout")
+            return
+        self._masks = self.eng._dev(np.ascontiguousarray(masks, np.uint8).ravel(), torch.uint8)
+        _lib.check(self.lib.mzs_train_set_dropout(self.eng.h, C.c_void_p(self._masks.data_ptr()),
+                                                  self._masks.numel(), C.c_uint64(0)), "mzs_train_set_dropout")
 
     def current_lr(self):
         return scheduled_lr(self.sch, self.lr, self.epoch, self.count)

@@ -198,7 +198,7 @@ def test_vision_odd_head_shapes_equal_oracle(A, Sd, H, L):
 def test_vision_muzero_drop_in():
     """Muzero(model_structure='vision_model'): the reference's wrapper surface (muzero_model.py:828-905)
     — (1, 3, 98, 98) observations, (1, 3, 7, 7) hidden states — against the reference's own outputs, a
-    batched search through Monte_carlo_tree_search.run_batch, and train() refusing."""
+    batched search through Monte_carlo_tree_search.run_batch (train(): tests/test_gpu_vision_train.py)."""
     import torch
     from muzero_amd.model import Muzero
     from muzero_amd.search import Monte_carlo_tree_search
@@ -222,16 +222,3 @@ def test_vision_muzero_drop_in():
     assert value_close(rew, fx["dyn_reward"][3])
     res = Monte_carlo_tree_search(discount=0.997).run_batch(obs[:5], 10, mz, True, seeds=np.arange(5) + 3)
     assert res.policy.shape == (5, 2) and np.all(res.policy.sum(axis=1) == 10)
-    with pytest.raises(NotImplementedError):
-        mz.train(None)
-
-
-def test_vision_training_is_refused():
-    from muzero_amd import _lib
-    from muzero_amd.train import Trainer
-    d, blob = fixture_weights("visA")
-    eng = engine_for(d, 1)
-    eng.set_weights(blob)
-    with pytest.raises(_lib.MzsError):
-        Trainer(eng, 5, 16)
-    eng.close()

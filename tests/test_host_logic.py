@@ -68,8 +68,6 @@ def test_blob_layout_and_model_wrapper():
     assert vw["r_ds_conv_in"].shape == (1, 3, 3, 3) and vw["d_conv"].shape == (3, 4, 3, 3)
     assert vw["p_p_out_w"].shape == (4, 32) and vw["d_fc_in_w"].shape == (32, 147) and "d_fc_mid_w" in vw
     assert np.all(vw["r_ds_res_in_bn_var"] == 1) and np.all(vw["p_res_bn_b"] == 0)
-    with pytest.raises(NotImplementedError):
-        vz.train(None)
     lz = Muzero(model_structure="lstm_model", observation_space_dimensions=4, action_space_dimensions=2,
                 state_space_dimensions=31, hidden_layer_dimensions=64, number_of_hidden_layer=2)
     assert lz.dims == (4, 2, 31, 64, 2, 1)
