@@ -270,3 +270,63 @@ def test_bench_refuses_more_ranks_than_gpus():
         assert r.returncode != 0
         assert "GPU(s) are visible" in r.stderr
         assert '"n_gpus"' not in r.stdout
+
+
+VISION_TRAIN_WORKER = r'''
+import os, sys
+import numpy as np, torch
+sys.path.insert(0, os.environ["MZ_ROOT"]); sys.path.insert(0, os.path.join(os.environ["MZ_ROOT"], "tests"))
+sys.path.insert(0, os.path.join(os.environ["MZ_ROOT"], "oracle"))
+from muzero_amd import shard, train
+import mz_vision_train_oracle as vo
+from test_vision_train_oracle import step_inputs
+from conftest import load_golden
+import torch.distributed as dist
+rank, world = shard.init("gloo")
+fx = load_golden("train_visA_K3_B6.npz")
+dims, K, B = fx["dims"], int(fx["K"]), int(fx["B"])
+n = B // world; sl = slice(rank * n, (rank + 1) * n)
+kw = step_inputs(fx, 0)
+# this rank's rows of every Dropout2d call's (B, C) mask
+masks, p = [], 0
+for c in fx["s0_mask_calls"]:
+    masks.append(kw["masks"][p:p + B * c].reshape(B, c)[sl].ravel()); p += B * c
+out = vo.train_grad(fx["blob0"], dims, K, kw["obs"][sl], kw["actions"][:, sl], kw["tv"][:, sl], kw["tr"][:, sl],
+                    kw["tpol"][:, sl], kw["is_ratio"][sl], np.concatenate(masks), inv_global_batch=1.0 / B)
+opt = vo.Optimizer("adam", fx["blob0"].size, dims)
+# the bucket as mzs_train_grad fills it: gradient, with the running statistics' slots holding this shard's
+# share of their change; then ONE all-reduce; then the optimizer adds the summed change to the blob
+slots = out["grad"].astype(np.float32)
+slots[opt.is_stat] = ((out["running"] - fx["blob0"])[opt.is_stat] * (n / B)).astype(np.float32)
+bucket, grad, loss = train.make_bucket(slots.size, K)
+grad.copy_(torch.from_numpy(slots)); loss.copy_(torch.from_numpy(out["losses"].astype(np.float32)))
+assert train.allreduce_gradient(bucket) == world
+g = grad.numpy()
+running = fx["blob0"] + np.where(opt.is_stat, g, 0.0)
+blob = opt.apply(fx["blob0"], np.where(opt.is_stat, 0.0, g), running, float(fx["lr"]))
+np.savez(os.environ["MZ_OUT"] + f".{rank}.npz", blob=blob, grad=g, loss=loss.numpy(), own_running=out["running"])
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_vision_data_parallel_training_step_two_ranks(tmp_path):
+    """vision_model on two ranks: BatchNorm statistics are per shard (as torch.nn.DataParallel's replicas compute
+    them, muzero_model.py:333-340), the gradient bucket carries the running statistics' change in their own
+    slots, ONE all-reduce, and both replicas end with identical weights whose running statistics are the mean
+    of the two shards'."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import mz_vision_train_oracle as vo
+    from conftest import load_golden
+    out = str(tmp_path / "vdp")
+    run_two_ranks(tmp_path, "vision_train_worker.py", VISION_TRAIN_WORKER, out)
+    r0, r1 = np.load(out + ".0.npz"), np.load(out + ".1.npz")
+    assert np.array_equal(r0["blob"], r1["blob"]) and np.array_equal(r0["grad"], r1["grad"])
+    fx = load_golden("train_visA_K3_B6.npz")
+    stat = vo.Optimizer("adam", fx["blob0"].size, fx["dims"]).is_stat
+    mean_running = 0.5 * (r0["own_running"] + r1["own_running"])
+    assert not np.array_equal(r0["own_running"][stat], r1["own_running"][stat])
+    assert np.abs(r0["blob"][stat] - mean_running[stat]).max() <= 1e-6
+    assert np.isfinite(r0["blob"]).all() and not np.array_equal(r0["blob"][~stat], fx["blob0"][~stat])
+    # loss terms: the two shards' shares of the batch mean add up to a full-batch mean of per-shard-normalised nets
+    assert np.isfinite(r0["loss"]).all() and r0["loss"][-1] > 0

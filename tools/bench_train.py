@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--lstm", action="store_true", help="also time the 'lstm_model' shape (config C4)")
+    ap.add_argument("--vision", action="store_true", help="also time the 'vision_model' shape (98 x 98 x 3 images)")
+    ap.add_argument("--only-vision", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)
     args = ap.parse_args()
 
@@ -50,6 +52,9 @@ def main():
     cases = [(mlp, 0, 5, 128), (mlp, 0, 10, 128), (mlp, 0, 5, 1024)]
     if args.lstm:     # BASELINE config C4 shape; every head's LSTM runs along the batch axis
         cases += [(lstm, 1, 5, 128), (lstm, 1, 5, 512)]
+    if args.vision or args.only_vision:
+        vis = np.load(os.path.join(ROOT, "tests", "golden", "weights_visA.npz"))
+        cases = ([] if args.only_vision else cases) + [(vis, 2, 5, 32), (vis, 2, 5, 128), (vis, 2, 5, 512)]
     for w, kind, K, B in cases:
         dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (kind,)
         rs = np.random.RandomState(rank)
@@ -57,7 +62,8 @@ def main():
         eng.set_weights(w["blob"])
         tr = Trainer(eng, K, B, "adam", 0.01, "cosineannealinglr", 10000)
         dev = eng.device
-        obs = torch.as_tensor(rs.uniform(-1, 1, (B, dims[0])).astype(np.float32)).to(dev)
+        obs_shape = (B, 3, 98, 98) if kind == 2 else (B, dims[0])
+        obs = torch.as_tensor(rs.uniform(0 if kind == 2 else -1, 1, obs_shape).astype(np.float32)).to(dev)
         act = torch.zeros((K, B, dims[1]), device=dev)
         act[..., 0] = 1.0
         tv = torch.as_tensor(rs.uniform(0, 50, (K, B)).astype(np.float32)).to(dev)
@@ -89,7 +95,7 @@ def main():
             ar_us = 1e6 * shard.max_over_ranks(time.perf_counter() - t0, dev) / n
         shard.assert_replicas_identical(tr.weights(), dev)          # replicas stayed bit-identical
         if rank == 0:
-            print(json.dumps({"metric": "training step wall time", "model": "lstm_model" if kind else "mlp_model",
+            print(json.dumps({"metric": "training step wall time", "model": ("mlp_model", "lstm_model", "vision_model")[kind],
                               "unroll": K, "batch_per_gpu": B,
                               "n_gpus": world, "global_batch": B * world, "ms_per_step": 1e3 * dt,
                               "samples_per_s": B * world / dt, "allreduce_us": ar_us,
