@@ -28,8 +28,10 @@ int64_t vis_train_mask_count(VisTrain* vt, int batch);
 const unsigned char* vis_train_stat_flags(const VisTrain* vt);
 
 /* forward (training mode) + losses + backward; arguments as mzs_train_grad (include/mzsearch.h).
+ * quad_store_dev: the search kernels' store of the Linear layers (mzs_vision.h vis_lin_offsets), which the forward
+ * pass reads too.
  * masks_dev: vis_train_mask_count(batch) bytes, or null = drawn on the device from (seed, step). */
-int vis_train_grad(VisTrain* vt, const float* blob_dev, int batch, const float* obs_dev, const float* actions_dev,
+int vis_train_grad(VisTrain* vt, const float* blob_dev, const float* quad_store_dev, int batch, const float* obs_dev, const float* actions_dev,
                    const float* tv_dev, const float* tr_dev, const float* tp_dev, const float* is_ratio_dev,
                    float inv_global_batch, int loss_value, int loss_reward, const unsigned char* masks_dev,
                    uint64_t seed, uint64_t step, float* grad_dev, float* loss_dev, float* priority_dev,

@@ -23,6 +23,7 @@
  */
 #include "mzs_vision_train.h"
 
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <vector>
@@ -40,17 +41,56 @@ constexpr int kS4 = MZS_VIS_S4 * MZS_VIS_S4; /* 49 */
 
 inline unsigned nblk(size_t n) { return (unsigned)((n + kT - 1) / kT); }
 
+/* reductions over n elements: chunks of >= 1024 elements (four per thread, all requested at once), at most 512 */
+struct Chunks {
+    int n;
+    size_t per;
+};
+inline Chunks chunks_of(size_t n, size_t min_per = (size_t)kT * 4) {
+    size_t per = min_per;
+    if ((n + per - 1) / per > 512) per = (n + 511) / 512;
+    return Chunks{(int)((n + per - 1) / per), per};
+}
+
+/* sum of one fp64 value per lane of a wavefront, fixed order; the total in lane 0 */
+__device__ __forceinline__ double wave_sum64(double v) {
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, kWave);
+    return v;
+}
+
+/* sum over the kT threads of a block, fixed order; the total in thread 0 only */
 __device__ __forceinline__ double block_sum(double v, double* red) {
-    red[threadIdx.x] = v;
+    v = wave_sum64(v);
+    if ((threadIdx.x & (kWave - 1)) == 0) red[threadIdx.x / kWave] = v;
     __syncthreads();
-    for (int s = kT / 2; s > 0; s >>= 1) {
-        if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
-        __syncthreads();
-    }
-    const double r = red[0];
+    double r = 0.0;
+    if (threadIdx.x == 0)
+        for (int w = 0; w < kT / kWave; ++w) r += red[w];
     __syncthreads();
     return r;
 }
+
+/* the chunks of a two-step reduction, added by one wavefront (lane k takes chunks k, k + 64, ...); stride in
+ * doubles between consecutive chunks; the total in lane 0 */
+__device__ __forceinline__ double wave_sum_chunks(const double* __restrict__ part, int chunks, size_t stride, int lane) {
+    double v = 0.0;
+    for (int k = lane; k < chunks; k += kWave) v += part[(size_t)k * stride];
+    return wave_sum64(v);
+}
+
+/* the second step of a weight-gradient reduction, done by the waves of the NEXT kernel on the stream (the layer's
+ * data-gradient kernel) before their own work: item i = the chunks of part[.][i] added into dst[i] */
+__device__ __forceinline__ void finish_items(const double* __restrict__ part, int items, int chunks,
+                                             float* __restrict__ dst) {
+    if (!part) return;
+    const int lane = threadIdx.x % kWave;
+    for (int i = blockIdx.x * (kT / kWave) + threadIdx.x / kWave; i < items; i += gridDim.x * (kT / kWave)) {
+        const double acc = wave_sum_chunks(part + i, chunks, (size_t)items, lane);
+        if (lane == 0) dst[i] += (float)acc;
+    }
+}
+
+constexpr int kU = 4; /* elements a thread of a reduction requests before it adds any */
 
 /* ------------------------------------------------------------------ 3x3 convolution, padding 1, no bias */
 __global__ void __launch_bounds__(kT) k_vt_conv3_fwd(const float* __restrict__ x, const float* __restrict__ w,
@@ -78,7 +118,9 @@ __global__ void __launch_bounds__(kT) k_vt_conv3_fwd(const float* __restrict__ x
 
 __global__ void __launch_bounds__(kT) k_vt_conv3_bwd_x(const float* __restrict__ dy, const float* __restrict__ w,
                                                        float* __restrict__ dx, int B, int Ci, int Co, int S, int So,
-                                                       int stride) {
+                                                       int stride, const double* __restrict__ part, int chunks,
+                                                       float* __restrict__ gw) {
+    finish_items(part, Co * Ci * 9, chunks, gw); /* of the k_vt_conv3_bwd_w launched before this kernel */
     const size_t i = (size_t)blockIdx.x * kT + threadIdx.x;
     if (i >= (size_t)B * Ci * S * S) return;
     const int ix = (int)(i % S), iy = (int)((i / S) % S), ci = (int)((i / ((size_t)S * S)) % Ci);
@@ -103,103 +145,245 @@ __global__ void __launch_bounds__(kT) k_vt_conv3_bwd_x(const float* __restrict__
     dx[i] += acc;
 }
 
-/* one block per weight element: sum over samples and output pixels */
-__global__ void __launch_bounds__(kT) k_vt_conv3_bwd_w(const float* __restrict__ x, const float* __restrict__ dy,
-                                                       float* __restrict__ gw, int B, int Ci, int Co, int S, int So,
-                                                       int stride) {
+/* Reductions over (sample, pixel) run in two steps: block (item, chunk) sums its chunk of the n elements into
+ * part[chunk][item] (fp64; at most 64 chunks), then ONE WAVEFRONT per item adds the chunks, a lane each, in a
+ * fixed shuffle tree — enough blocks to fill the chip (a per-channel or per-weight sum has 1..108 items), a
+ * fixed summation order, no atomics.  The BatchNorm sums are finished inside the kernels that consume them. */
+__global__ void __launch_bounds__(kT) k_vt_accum_fin(const double* __restrict__ part, int items, int chunks,
+                                                     float* __restrict__ dst) {
+    const int i = blockIdx.x * (kT / kWave) + threadIdx.x / kWave, lane = threadIdx.x % kWave;
+    if (i >= items) return;
+    const double acc = wave_sum_chunks(part + i, chunks, (size_t)items, lane);
+    if (lane == 0) dst[i] += (float)acc;
+}
+
+/* block (weight element, chunk): sum over the chunk's samples and output pixels (small layers: nine times the
+ * blocks of the kernel below) */
+__global__ void __launch_bounds__(kT) k_vt_conv3_bwd_w1(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        double* __restrict__ part, float* __restrict__ gw, int B, int Ci,
+                                                        int Co, int S, int So, int stride, size_t per) {
     __shared__ double red[kT];
     const int wi = blockIdx.x;
     const int kx = wi % 3, ky = (wi / 3) % 3, ci = (wi / 9) % Ci, co = wi / (9 * Ci);
-    const size_t n = (size_t)B * So * So;
+    const size_t n_all = (size_t)B * So * So, j0 = (size_t)blockIdx.y * per;
+    const size_t n = j0 + per < n_all ? j0 + per : n_all;
     double acc = 0.0;
-    for (size_t j = threadIdx.x; j < n; j += kT) {
-        const int ox = (int)(j % So), oy = (int)((j / So) % So), b = (int)(j / ((size_t)So * So));
-        const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
-        if (iy < 0 || iy >= S || ix < 0 || ix >= S) continue;
-        acc += (double)dy[(((size_t)b * Co + co) * So + oy) * So + ox] *
-               (double)x[(((size_t)b * Ci + ci) * S + iy) * S + ix];
+    for (size_t base = j0 + threadIdx.x; base < n; base += (size_t)kU * kT) {
+        float dv[kU], xv[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t j = base + (size_t)u * kT;
+            const int ox = (int)(j % So), oy = (int)((j / So) % So), b = (int)(j / ((size_t)So * So));
+            const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+            const bool ok = j < n && iy >= 0 && iy < S && ix >= 0 && ix < S;
+            const size_t di = ok ? (((size_t)b * Co + co) * So + oy) * So + ox : 0;
+            const size_t xi = ok ? (((size_t)b * Ci + ci) * S + iy) * S + ix : 0;
+            const float d0 = dy[di], x0 = x[xi];
+            dv[u] = ok ? d0 : 0.0f;
+            xv[u] = x0;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) acc += (double)dv[u] * (double)xv[u];
     }
     acc = block_sum(acc, red);
-    if (threadIdx.x == 0) gw[wi] += (float)acc;
+    if (threadIdx.x == 0) {
+        if (gridDim.y == 1)
+            gw[wi] += (float)acc;
+        else
+            part[(size_t)blockIdx.y * gridDim.x + wi] = acc;
+    }
+}
+
+/* block ((co, ci) pair, chunk): the nine taps' sums over the chunk's samples and output pixels — dy is read
+ * once for the nine, the nine inputs of an output pixel are neighbours */
+__global__ void __launch_bounds__(kT) k_vt_conv3_bwd_w(const float* __restrict__ x, const float* __restrict__ dy,
+                                                       double* __restrict__ part, float* __restrict__ gw, int B, int Ci,
+                                                       int Co, int S, int So, int stride, size_t per) {
+    __shared__ double red[kT];
+    const int pair = blockIdx.x, ci = pair % Ci, co = pair / Ci;
+    const size_t n_all = (size_t)B * So * So, j0 = (size_t)blockIdx.y * per;
+    const size_t n = j0 + per < n_all ? j0 + per : n_all;
+    double acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) acc[t] = 0.0;
+    for (size_t base = j0 + threadIdx.x; base < n; base += (size_t)kU * kT) {
+        float dv[kU], xv[kU][9];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t j = base + (size_t)u * kT;
+            const bool ok = j < n;
+            const int ox = (int)(j % So), oy = (int)((j / So) % So), b = ok ? (int)(j / ((size_t)So * So)) : 0;
+            dv[u] = ok ? dy[(((size_t)b * Co + co) * So + oy) * So + ox] : 0.0f;
+            const float* xc = x + ((size_t)b * Ci + ci) * S * S;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int iy = oy * stride + ky - 1, ix = ox * stride + kx - 1;
+                    xv[u][ky * 3 + kx] = ok && iy >= 0 && iy < S && ix >= 0 && ix < S ? xc[(size_t)iy * S + ix] : 0.0f;
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u)
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[t] += (double)dv[u] * (double)xv[u][t];
+    }
+    const int items = Co * Ci * 9;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const double r = block_sum(acc[t], red);
+        if (threadIdx.x == 0) {
+            const int wi = pair * 9 + t;
+            if (gridDim.y == 1)
+                gw[wi] += (float)r;
+            else
+                part[(size_t)blockIdx.y * items + wi] = r;
+        }
+    }
 }
 
 /* ------------------------------------------------------------------ BatchNorm2d (training) + relu + Dropout2d */
-__global__ void __launch_bounds__(kT) k_vt_bn_stats(const float* __restrict__ x, float* mean, float* rstd,
-                                                    float* run_mean, float* run_var, int B, int C, int SS) {
+/* block (channel, chunk) -> part[chunk][2 C] = (sum x, sum x^2) */
+__global__ void __launch_bounds__(kT) k_vt_bn_stats(const float* __restrict__ x, double* __restrict__ part, int B,
+                                                    int C, int SS, size_t per) {
     __shared__ double red[kT];
     const int c = blockIdx.x;
-    const size_t n = (size_t)B * SS;
+    const size_t n_all = (size_t)B * SS, j0 = (size_t)blockIdx.y * per;
+    const size_t n = j0 + per < n_all ? j0 + per : n_all;
     double s = 0.0, q = 0.0;
-    for (size_t j = threadIdx.x; j < n; j += kT) {
-        const double v = (double)x[((size_t)(j / SS) * C + c) * SS + j % SS];
-        s += v;
-        q += v * v;
+    for (size_t base = j0 + threadIdx.x; base < n; base += (size_t)kU * kT) {
+        float xv[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t j = base + (size_t)u * kT;
+            xv[u] = j < n ? x[((size_t)(j / SS) * C + c) * SS + j % SS] : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            s += (double)xv[u];
+            q += (double)xv[u] * (double)xv[u];
+        }
     }
     s = block_sum(s, red);
     q = block_sum(q, red);
     if (threadIdx.x == 0) {
-        const double m = s / (double)n;
-        double var = q / (double)n - m * m;
-        var = var > 0.0 ? var : 0.0;
-        mean[c] = (float)m;
-        rstd[c] = (float)(1.0 / sqrt(var + 1e-5));
-        /* torch: running = (1 - momentum) running + momentum stat, momentum 0.1, unbiased variance */
-        run_mean[c] = 0.9f * run_mean[c] + 0.1f * (float)m;
-        run_var[c] = 0.9f * run_var[c] + 0.1f * (float)(var * ((double)n / ((double)n - 1.0)));
+        part[((size_t)blockIdx.y * C + c) * 2] = s;
+        part[((size_t)blockIdx.y * C + c) * 2 + 1] = q;
     }
 }
+/* the chunks of k_vt_bn_stats -> mean and 1 / sqrt(var + eps) of channel c (wave-uniform result in every lane's
+ * return is NOT given: lane 0 holds it) */
+__device__ __forceinline__ void bn_finish_stats(const double* __restrict__ part, int chunks, int C, int c, size_t n,
+                                                int lane, double* m_out, double* var_out) {
+    const double s = wave_sum_chunks(part + 2 * c, chunks, 2 * (size_t)C, lane);
+    const double q = wave_sum_chunks(part + 2 * c + 1, chunks, 2 * (size_t)C, lane);
+    const double m = s / (double)n;
+    const double var = q / (double)n - m * m;
+    *m_out = m;
+    *var_out = var > 0.0 ? var : 0.0;
+}
 
-/* y = relu(gamma xhat + beta) * (mask ? 2 mask : 1) */
-__global__ void __launch_bounds__(kT) k_vt_bn_act_fwd(const float* __restrict__ x, const float* __restrict__ mean,
-                                                      const float* __restrict__ rstd, const float* __restrict__ gamma,
+/* y = relu(gamma xhat + beta) * (mask ? 2 mask : 1).  Every block finishes the batch statistics from the chunk
+ * sums itself (its first wave, a lane per chunk: the same numbers in every block); block 0 also keeps them for
+ * the backward pass and moves the running statistics (torch: running = 0.9 running + 0.1 stat, unbiased var). */
+__global__ void __launch_bounds__(kT) k_vt_bn_act_fwd(const float* __restrict__ x, const double* __restrict__ part,
+                                                      int chunks, float* mean, float* rstd, float* run_mean,
+                                                      float* run_var, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta,
                                                       const unsigned char* __restrict__ mask, float* __restrict__ y,
                                                       int B, int C, int SS) {
+    __shared__ float s_mean[4], s_rstd[4];
+    if (threadIdx.x < kWave) {
+        const size_t n = (size_t)B * SS;
+        for (int c = 0; c < C; ++c) {
+            double m, var;
+            bn_finish_stats(part, chunks, C, c, n, threadIdx.x, &m, &var);
+            if (threadIdx.x == 0) {
+                s_mean[c] = (float)m;
+                s_rstd[c] = (float)(1.0 / sqrt(var + 1e-5));
+                if (blockIdx.x == 0) {
+                    mean[c] = s_mean[c];
+                    rstd[c] = s_rstd[c];
+                    run_mean[c] = 0.9f * run_mean[c] + 0.1f * (float)m;
+                    run_var[c] = 0.9f * run_var[c] + 0.1f * (float)(var * ((double)n / ((double)n - 1.0)));
+                }
+            }
+        }
+    }
+    __syncthreads();
     const size_t i = (size_t)blockIdx.x * kT + threadIdx.x;
     if (i >= (size_t)B * C * SS) return;
     const int c = (int)((i / SS) % C);
     const size_t bc = i / SS;
     const float f = mask ? (mask[bc] ? 2.0f : 0.0f) : 1.0f;
-    const float v = gamma[c] * ((x[i] - mean[c]) * rstd[c]) + beta[c];
+    const float v = gamma[c] * ((x[i] - s_mean[c]) * s_rstd[c]) + beta[c];
     y[i] = v > 0.0f ? v * f : 0.0f;
 }
 
-/* per channel: s1 = sum d, s2 = sum d xhat with d = dL/d(bn output); + the gradients of gamma and beta */
+/* per channel: s1 = sum d, s2 = sum d xhat with d = dL/d(bn output); block (channel, chunk) -> part[chunk][2 C] */
 __global__ void __launch_bounds__(kT) k_vt_bn_bwd_red(const float* __restrict__ x, const float* __restrict__ mean,
                                                       const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta,
                                                       const unsigned char* __restrict__ mask,
-                                                      const float* __restrict__ dy, double* sums, float* g_gamma,
-                                                      float* g_beta, int B, int C, int SS) {
+                                                      const float* __restrict__ dy, double* __restrict__ part, int B,
+                                                      int C, int SS, size_t per) {
     __shared__ double red[kT];
     const int c = blockIdx.x;
-    const size_t n = (size_t)B * SS;
+    const size_t n_all = (size_t)B * SS, j0 = (size_t)blockIdx.y * per;
+    const size_t n = j0 + per < n_all ? j0 + per : n_all;
     const float mc = mean[c], rc = rstd[c], gc = gamma[c], bc = beta[c];
     double s1 = 0.0, s2 = 0.0;
-    for (size_t j = threadIdx.x; j < n; j += kT) {
-        const size_t b = j / SS, i = (b * C + c) * SS + j % SS;
-        const float f = mask ? (mask[b * C + c] ? 2.0f : 0.0f) : 1.0f;
-        const float xh = (x[i] - mc) * rc;
-        const float d = gc * xh + bc > 0.0f ? dy[i] * f : 0.0f;
-        s1 += (double)d;
-        s2 += (double)d * (double)xh;
+    for (size_t base = j0 + threadIdx.x; base < n; base += (size_t)kU * kT) {
+        float xv[kU], dv[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t j = base + (size_t)u * kT;
+            const bool ok = j < n;
+            const size_t b = ok ? j / SS : 0, i = (b * C + c) * SS + (ok ? j % SS : 0);
+            const float f = !ok ? 0.0f : mask ? (mask[b * C + c] ? 2.0f : 0.0f) : 1.0f;
+            xv[u] = x[i];
+            dv[u] = dy[i] * f;
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const float xh = (xv[u] - mc) * rc;
+            const float d = gc * xh + bc > 0.0f ? dv[u] : 0.0f;
+            s1 += (double)d;
+            s2 += (double)d * (double)xh;
+        }
     }
     s1 = block_sum(s1, red);
     s2 = block_sum(s2, red);
     if (threadIdx.x == 0) {
-        sums[2 * c] = s1;
-        sums[2 * c + 1] = s2;
-        g_gamma[c] += (float)s2;
-        g_beta[c] += (float)s1;
+        part[((size_t)blockIdx.y * C + c) * 2] = s1;
+        part[((size_t)blockIdx.y * C + c) * 2 + 1] = s2;
     }
 }
-
 __global__ void __launch_bounds__(kT) k_vt_bn_bwd_x(const float* __restrict__ x, const float* __restrict__ mean,
                                                     const float* __restrict__ rstd, const float* __restrict__ gamma,
                                                     const float* __restrict__ beta,
                                                     const unsigned char* __restrict__ mask,
-                                                    const float* __restrict__ dy, const double* __restrict__ sums,
+                                                    const float* __restrict__ dy, const double* __restrict__ part,
+                                                    int chunks, float* g_gamma, float* g_beta,
                                                     float* __restrict__ dx, int B, int C, int SS) {
+    /* every block finishes the two per-channel sums from the chunks of k_vt_bn_bwd_red (first wave, a lane per
+     * chunk); block 0 adds them to the gradients of gamma and beta */
+    __shared__ double sums[8];
+    if (threadIdx.x < kWave) {
+        for (int c = 0; c < C; ++c) {
+            const double s1 = wave_sum_chunks(part + 2 * c, chunks, 2 * (size_t)C, threadIdx.x);
+            const double s2 = wave_sum_chunks(part + 2 * c + 1, chunks, 2 * (size_t)C, threadIdx.x);
+            if (threadIdx.x == 0) {
+                sums[2 * c] = s1;
+                sums[2 * c + 1] = s2;
+                if (blockIdx.x == 0) {
+                    g_gamma[c] += (float)s2;
+                    g_beta[c] += (float)s1;
+                }
+            }
+        }
+    }
+    __syncthreads();
     const size_t i = (size_t)blockIdx.x * kT + threadIdx.x;
     if (i >= (size_t)B * C * SS) return;
     const int c = (int)((i / SS) % C);
@@ -303,7 +487,10 @@ __global__ void __launch_bounds__(kT) k_vt_conv1_fwd(const float* __restrict__ x
     y[i] = acc;
 }
 __global__ void __launch_bounds__(kT) k_vt_conv1_bwd_x(const float* __restrict__ dy, const float* __restrict__ w,
-                                                       float* __restrict__ dx, int B, int Ci, int Co) {
+                                                       float* __restrict__ dx, int B, int Ci, int Co,
+                                                       const double* __restrict__ part, int chunks,
+                                                       float* __restrict__ gw) {
+    finish_items(part, Co * Ci + Co, chunks, gw); /* of the k_vt_conv1_bwd_w launched before this kernel */
     const size_t i = (size_t)blockIdx.x * kT + threadIdx.x;
     if (i >= (size_t)B * Ci * kS4) return;
     const int p = (int)(i % kS4), ci = (int)((i / kS4) % Ci), b = (int)(i / ((size_t)Ci * kS4));
@@ -313,76 +500,134 @@ __global__ void __launch_bounds__(kT) k_vt_conv1_bwd_x(const float* __restrict__
 }
 /* blocks [0, Co Ci): weights; [Co Ci, Co Ci + Co): biases */
 __global__ void __launch_bounds__(kT) k_vt_conv1_bwd_w(const float* __restrict__ x, const float* __restrict__ dy,
-                                                       float* gw, float* gb, int B, int Ci, int Co) {
+                                                       double* __restrict__ part, float* __restrict__ gw, int B, int Ci,
+                                                       int Co, size_t per) {
     __shared__ double red[kT];
     const int wi = blockIdx.x;
     const bool is_bias = wi >= Co * Ci;
     const int co = is_bias ? wi - Co * Ci : wi / Ci, ci = is_bias ? 0 : wi % Ci;
-    const size_t n = (size_t)B * kS4;
+    const size_t n_all = (size_t)B * kS4, j0 = (size_t)blockIdx.y * per;
+    const size_t n = j0 + per < n_all ? j0 + per : n_all;
     double acc = 0.0;
-    for (size_t j = threadIdx.x; j < n; j += kT) {
-        const size_t b = j / kS4, p = j % kS4;
-        const double d = (double)dy[(b * Co + co) * kS4 + p];
-        acc += is_bias ? d : d * (double)x[(b * Ci + ci) * kS4 + p];
+    for (size_t base = j0 + threadIdx.x; base < n; base += (size_t)kU * kT) {
+        float dv[kU], xv[kU];
+#pragma unroll
+        for (int u = 0; u < kU; ++u) {
+            const size_t j = base + (size_t)u * kT;
+            const bool ok = j < n;
+            const size_t b = ok ? j / kS4 : 0, p = ok ? j % kS4 : 0;
+            dv[u] = ok ? dy[(b * Co + co) * kS4 + p] : 0.0f;
+            xv[u] = is_bias ? 1.0f : x[(b * Ci + ci) * kS4 + p];
+        }
+#pragma unroll
+        for (int u = 0; u < kU; ++u) acc += (double)dv[u] * (double)xv[u];
     }
     acc = block_sum(acc, red);
     if (threadIdx.x == 0) {
-        if (is_bias)
-            gb[co] += (float)acc;
-        else
+        if (gridDim.y == 1)
             gw[wi] += (float)acc;
+        else
+            part[(size_t)blockIdx.y * gridDim.x + wi] = acc;
     }
 }
 
 /* ------------------------------------------------------------------ Linear (+ relu) */
-__global__ void __launch_bounds__(kT) k_vt_linear_fwd(const float* __restrict__ x, const float* __restrict__ W,
+/* W in the quad layout of the search kernels' store (mzs_vision.h: element (k, n), k < 4 (K / 4), at
+ * ((k / 4) N + n) 4 + k % 4, the last K % 4 rows behind as [k][n]): thread (b, n) fetches four k per 16-byte
+ * load and neighbouring n touch neighbouring addresses; x[b][.] is the same address for the lanes of a row */
+__global__ void __launch_bounds__(kT) k_vt_linear_fwd(const float* __restrict__ x, const float* __restrict__ Wq,
                                                       const float* __restrict__ bias, float* __restrict__ y, int B,
                                                       int N, int K, int relu) {
     const size_t i = (size_t)blockIdx.x * kT + threadIdx.x;
     if (i >= (size_t)B * N) return;
     const int n = (int)(i % N), b = (int)(i / N);
     const float* xr = x + (size_t)b * K;
-    const float* wr = W + (size_t)n * K;
+    const float4* wq = reinterpret_cast<const float4*>(Wq) + n;
+    const int Q = K >> 2;
     float e = bias[n], o = 0.0f;
-    int k = 0;
-    for (; k + 1 < K; k += 2) {
-        e = __builtin_fmaf(wr[k], xr[k], e);
-        o = __builtin_fmaf(wr[k + 1], xr[k + 1], o);
+    constexpr int QB = 8; /* quads requested before the chains that consume them */
+    int q = 0;
+    for (; q + QB <= Q; q += QB) {
+        float4 w[QB];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) w[u] = wq[(size_t)(q + u) * N];
+#pragma unroll
+        for (int u = 0; u < QB; ++u) {
+            e = __builtin_fmaf(w[u].x, xr[4 * (q + u)], e);
+            o = __builtin_fmaf(w[u].y, xr[4 * (q + u) + 1], o);
+            e = __builtin_fmaf(w[u].z, xr[4 * (q + u) + 2], e);
+            o = __builtin_fmaf(w[u].w, xr[4 * (q + u) + 3], o);
+        }
     }
-    if (k < K) e = __builtin_fmaf(wr[k], xr[k], e);
+    for (; q < Q; ++q) {
+        const float4 w = wq[(size_t)q * N];
+        e = __builtin_fmaf(w.x, xr[4 * q], e);
+        o = __builtin_fmaf(w.y, xr[4 * q + 1], o);
+        e = __builtin_fmaf(w.z, xr[4 * q + 2], e);
+        o = __builtin_fmaf(w.w, xr[4 * q + 3], o);
+    }
+    const float* wt = Wq + (size_t)4 * Q * N + n;
+    for (int k = 4 * Q; k < K; ++k) e = __builtin_fmaf(wt[(size_t)(k - 4 * Q) * N], xr[k], e);
     const float v = e + o;
     y[i] = relu && v < 0.0f ? 0.0f : v;
 }
-/* dz = dy where the relu passed (in place on the gradient of the layer's output) */
-__global__ void __launch_bounds__(kT) k_vt_relu_mask(float* __restrict__ dy, const float* __restrict__ y, size_t n) {
-    const size_t i = (size_t)blockIdx.x * kT + threadIdx.x;
-    if (i < n && !(y[i] > 0.0f)) dy[i] = 0.0f;
-}
-__global__ void __launch_bounds__(kT) k_vt_linear_bwd_x(const float* __restrict__ dz, const float* __restrict__ W,
-                                                        float* __restrict__ dx, int B, int N, int K) {
+/* the Linear backward kernels take dz = dy where the relu passed (y > 0), formed on the fly when `relu` */
+__global__ void __launch_bounds__(kT) k_vt_linear_bwd_x(const float* __restrict__ dy, const float* __restrict__ y,
+                                                        const float* __restrict__ W, float* __restrict__ dx, int B,
+                                                        int N, int K, int relu) {
     const size_t i = (size_t)blockIdx.x * kT + threadIdx.x;
     if (i >= (size_t)B * K) return;
     const int k = (int)(i % K), b = (int)(i / K);
-    float acc = 0.0f;
-    for (int n = 0; n < N; ++n) acc = __builtin_fmaf(W[(size_t)n * K + k], dz[(size_t)b * N + n], acc);
-    dx[i] += acc;
-}
-/* threads [0, N K): weights; [N K, N K + N): biases */
-__global__ void __launch_bounds__(kT) k_vt_linear_bwd_w(const float* __restrict__ x, const float* __restrict__ dz,
-                                                        float* __restrict__ gw, float* __restrict__ gb, int B, int N,
-                                                        int K) {
-    const size_t i = (size_t)blockIdx.x * kT + threadIdx.x;
-    if (i >= (size_t)N * K + N) return;
-    double acc = 0.0;
-    if (i < (size_t)N * K) {
-        const int k = (int)(i % K), n = (int)(i / K);
-        for (int b = 0; b < B; ++b) acc += (double)dz[(size_t)b * N + n] * (double)x[(size_t)b * K + k];
-        gw[i] += (float)acc;
-    } else {
-        const int n = (int)(i - (size_t)N * K);
-        for (int b = 0; b < B; ++b) acc += (double)dz[(size_t)b * N + n];
-        gb[n] += (float)acc;
+    const float* dr = dy + (size_t)b * N;
+    const float* yr = y + (size_t)b * N;
+    float e = 0.0f, o = 0.0f;
+    int n = 0;
+    for (; n < N; n += 16) { /* sixteen weight rows in flight */
+        float w[16], d[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) { /* clamped addresses, selects after the loads: no branch between requests */
+            const bool ok = n + u < N;
+            const int nn = ok ? n + u : n;
+            w[u] = W[(size_t)nn * K + k];
+            const float yv = yr[nn], dv = dr[nn];
+            d[u] = !ok || (relu && !(yv > 0.0f)) ? 0.0f : dv;
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u += 2) {
+            e = __builtin_fmaf(w[u], d[u], e);
+            o = __builtin_fmaf(w[u + 1], d[u + 1], o);
+        }
     }
+    dx[i] += e + o;
+}
+/* threads [0, N K): weights; [N K, N K + N): biases; blockIdx.y = chunk of `per` samples -> part[chunk][item],
+ * or straight into the gradient when there is one chunk */
+__global__ void __launch_bounds__(kT) k_vt_linear_bwd_w(const float* __restrict__ x, const float* __restrict__ dy,
+                                                        const float* __restrict__ y, double* __restrict__ part,
+                                                        float* __restrict__ gw, int B, int N, int K, int per,
+                                                        int relu) {
+    const size_t i = (size_t)blockIdx.x * kT + threadIdx.x, items = (size_t)N * K + N;
+    if (i >= items) return;
+    const int b0 = blockIdx.y * per, b1 = min(b0 + per, B);
+    const bool is_w = i < (size_t)N * K;
+    const int k = is_w ? (int)(i % K) : 0, n = is_w ? (int)(i / K) : (int)(i - (size_t)N * K);
+    double acc = 0.0;
+    for (int b = b0; b < b1; b += 8) { /* eight samples in flight */
+        float d[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const bool ok = b + u < b1;
+            const size_t bb = ok ? (size_t)(b + u) : (size_t)b0;
+            d[u] = !ok || (relu && !(y[bb * N + n] > 0.0f)) ? 0.0f : dy[bb * N + n];
+            xv[u] = is_w ? x[bb * K + k] : 1.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += (double)d[u] * (double)xv[u];
+    }
+    if (gridDim.y == 1)
+        gw[i] += (float)acc;
+    else
+        part[(size_t)blockIdx.y * items + i] = acc;
 }
 
 /* ------------------------------------------------------------------ losses (muzero_model.py:650-713) */
@@ -435,6 +680,16 @@ __global__ void __launch_bounds__(kWave) k_vt_loss(const LossParams p) {
     }
 }
 
+/* sum of squares of the tensors inside the reference's l2 term: block partials (k_vt_finalize adds them) */
+__global__ void __launch_bounds__(kT) k_vt_l2sq(const float* __restrict__ blob, const unsigned char* __restrict__ l2_flag,
+                                                int n, double* __restrict__ part) {
+    __shared__ double red[kT];
+    const int i = blockIdx.x * kT + threadIdx.x;
+    const float w = i < n && l2_flag[i] ? blob[i] : 0.0f;
+    const double r = block_sum((double)w * (double)w, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = r;
+}
+
 struct FinalParams {
     const float* blob;
     const float* stat; /* running statistics after this step's forward passes (blob-sized copy) */
@@ -442,6 +697,7 @@ struct FinalParams {
     const unsigned char* l2_flag;
     const float* is_ratio;
     const float* loss_buf;
+    const double* sq_part; /* k_vt_l2sq: one partial per gradient block */
     float* grad;
     float* loss_out;
     int n_params, B, K;
@@ -468,8 +724,7 @@ __global__ void __launch_bounds__(kT) k_vt_finalize(const FinalParams p, int n_g
         return;
     }
     double sq = 0.0;
-    for (int i = threadIdx.x; i < p.n_params; i += kT)
-        if (p.l2_flag[i]) sq += (double)p.blob[i] * (double)p.blob[i];
+    for (int i = threadIdx.x; i < n_grad_blocks; i += kT) sq += p.sq_part[i];
     double tot = 0.0, wsum = 0.0;
     for (int b = threadIdx.x; b < B; b += kT) {
         const double wb = (double)((p.is_ratio ? p.is_ratio[b] : 1.0f) * p.inv_batch);
@@ -481,12 +736,13 @@ __global__ void __launch_bounds__(kT) k_vt_finalize(const FinalParams p, int n_g
     sq = block_sum(sq, red);
     tot = block_sum(tot, red);
     wsum = block_sum(wsum, red);
-    for (int q = threadIdx.x; q < n_terms; q += kT) {
-        double s = 0.0;
-        for (int b = 0; b < B; ++b) s += (double)p.loss_buf[(size_t)b * n_terms + q];
-        p.loss_out[q] = (float)(s * (double)p.inv_batch);
-    }
     if (threadIdx.x == 0) p.loss_out[n_terms] = (float)(tot + wsum * 1e-4 * sq);
+    for (int q = 0; q < n_terms; ++q) {
+        double s = 0.0;
+        for (int b = threadIdx.x; b < B; b += kT) s += (double)p.loss_buf[(size_t)b * n_terms + q];
+        s = block_sum(s, red);
+        if (threadIdx.x == 0) p.loss_out[q] = (float)(s * (double)p.inv_batch);
+    }
 }
 
 /* Dropout2d(p = 0.5) masks from a counter-based generator: bit 40 of splitmix64(seed, step, index).
@@ -522,6 +778,7 @@ struct VisTrain {
     float* grads = nullptr;
     float* stat = nullptr;
     float* loss_buf = nullptr;
+    double* sq_part = nullptr;
     unsigned char* stat_flag = nullptr;
     unsigned char* l2_flag = nullptr;
     unsigned char* own_masks = nullptr;
@@ -532,9 +789,14 @@ struct VisTrain {
     int B = 0;
     hipStream_t st = nullptr;
     const float* blob = nullptr;
+    const float* quads = nullptr; /* the search kernels' quad store of the Linear layers (refreshed by every apply) */
     float* gw = nullptr;
     const unsigned char* masks = nullptr;
     const float* actions = nullptr;
+    hipStream_t main_st = nullptr; /* the caller's stream */
+    hipStream_t side = nullptr;    /* the prediction passes run beside the dynamics chain (vis_train_create) */
+    std::vector<hipEvent_t> events;
+    size_t n_events = 0;
     std::vector<std::function<void()>> tape;
     std::vector<void*> allocs;
 
@@ -554,6 +816,28 @@ struct VisTrain {
     void back(std::function<void()> fn) {
         if (!dry && !no_grad) tape.push_back(std::move(fn));
     }
+    hipEvent_t event() {
+        if (n_events == events.size()) {
+            hipEvent_t e;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) abort();
+            events.push_back(e);
+        }
+        return events[n_events++];
+    }
+    /* `to` continues after what `from` holds so far — in the forward pass now, and the other way round at the
+     * same point of the backward replay */
+    void link(hipStream_t from, hipStream_t to) {
+        if (dry || from == to) return;
+        hipEvent_t e = event();
+        (void)hipEventRecord(e, from);
+        (void)hipStreamWaitEvent(to, e, 0);
+        if (no_grad) return;
+        hipEvent_t r = event();
+        tape.push_back([=] {
+            (void)hipEventRecord(r, to);
+            (void)hipStreamWaitEvent(from, r, 0);
+        });
+    }
 };
 
 #define VT_LAUNCH(vt, kernel, blocks, ...)                                                   \
@@ -571,13 +855,23 @@ Tn conv3(VisTrain& v, const Tn& x, size_t w_off, int Ci, int Co, int stride, con
     float* gw = v.gw + w_off;
     const Tn r = res ? *res : Tn{};
     const bool has_res = res != nullptr;
-    VisTrain* pv = &v;
+    const int items = Co * Ci * 9;
+    const Chunks ch = chunks_of((size_t)B * So * So);
+    double* part = v.no_grad ? nullptr : reinterpret_cast<double*>(v.scratch(2 * (size_t)items * ch.n));
+    const hipStream_t st = v.st;
     v.back([=] {
-        VisTrain& t = *pv;
-        if (has_res) hipLaunchKernelGGL(k_vt_axpy, dim3(nblk(y.n)), dim3(kT), 0, t.st, r.g, y.g, 1.0f, y.n);
-        hipLaunchKernelGGL(k_vt_conv3_bwd_w, dim3(Co * Ci * 9), dim3(kT), 0, t.st, x.v, y.g, gw, B, Ci, Co, S, So, stride);
+        if (has_res) hipLaunchKernelGGL(k_vt_axpy, dim3(nblk(y.n)), dim3(kT), 0, st, r.g, y.g, 1.0f, y.n);
+        if ((size_t)B * So * So >= (size_t)1 << 16) /* large layers: one block per (co, ci), dy read once for nine taps */
+            hipLaunchKernelGGL(k_vt_conv3_bwd_w, dim3(Co * Ci, ch.n), dim3(kT), 0, st, x.v, y.g, part, gw, B, Ci, Co, S,
+                               So, stride, ch.per);
+        else
+            hipLaunchKernelGGL(k_vt_conv3_bwd_w1, dim3(items, ch.n), dim3(kT), 0, st, x.v, y.g, part, gw, B, Ci, Co, S,
+                               So, stride, ch.per);
         if (need_dx)
-            hipLaunchKernelGGL(k_vt_conv3_bwd_x, dim3(nblk(x.n)), dim3(kT), 0, t.st, y.g, w, x.g, B, Ci, Co, S, So, stride);
+            hipLaunchKernelGGL(k_vt_conv3_bwd_x, dim3(nblk(x.n)), dim3(kT), 0, st, y.g, w, x.g, B, Ci, Co, S, So, stride,
+                               ch.n > 1 ? (const double*)part : nullptr, ch.n, gw);
+        else if (ch.n > 1)
+            hipLaunchKernelGGL(k_vt_accum_fin, dim3((items + 3) / 4), dim3(kT), 0, st, (const double*)part, items, ch.n, gw);
     });
     return y;
 }
@@ -588,7 +882,8 @@ Tn bn_act(VisTrain& v, const Tn& x, const mzs_vis_bn& bn, bool dropout) {
     Tn y = v.tensor(C, x.s);
     float* mean = v.scratch(C);
     float* rstd = v.scratch(C);
-    double* sums = reinterpret_cast<double*>(v.scratch(4 * (size_t)C));
+    const Chunks ch = chunks_of((size_t)B * SS);
+    double* part = reinterpret_cast<double*>(v.scratch(4 * (size_t)C * ch.n));
     const unsigned char* mask = nullptr;
     if (dropout) {
         mask = v.masks ? v.masks + v.mask_pos : nullptr;
@@ -596,17 +891,20 @@ Tn bn_act(VisTrain& v, const Tn& x, const mzs_vis_bn& bn, bool dropout) {
     }
     const float* gamma = v.blob + bn.w;
     const float* beta = v.blob + bn.b;
-    VT_LAUNCH(v, k_vt_bn_stats, C, x.v, mean, rstd, v.stat + bn.mean, v.stat + bn.var, B, C, SS);
-    VT_LAUNCH(v, k_vt_bn_act_fwd, nblk(y.n), x.v, mean, rstd, gamma, beta, mask, y.v, B, C, SS);
+    double* part2 = v.no_grad ? nullptr : reinterpret_cast<double*>(v.scratch(4 * (size_t)C * ch.n));
+    if (!v.dry) {
+        hipLaunchKernelGGL(k_vt_bn_stats, dim3(C, ch.n), dim3(kT), 0, v.st, x.v, part, B, C, SS, ch.per);
+        hipLaunchKernelGGL(k_vt_bn_act_fwd, dim3(nblk(y.n)), dim3(kT), 0, v.st, x.v, (const double*)part, ch.n, mean,
+                           rstd, v.stat + bn.mean, v.stat + bn.var, gamma, beta, mask, y.v, B, C, SS);
+    }
     float* gg = v.gw + bn.w;
     float* gb = v.gw + bn.b;
-    VisTrain* pv = &v;
+    const hipStream_t st = v.st;
     v.back([=] {
-        VisTrain& t = *pv;
-        hipLaunchKernelGGL(k_vt_bn_bwd_red, dim3(C), dim3(kT), 0, t.st, x.v, mean, rstd, gamma, beta, mask, y.g, sums,
-                           gg, gb, B, C, SS);
-        hipLaunchKernelGGL(k_vt_bn_bwd_x, dim3(nblk(x.n)), dim3(kT), 0, t.st, x.v, mean, rstd, gamma, beta, mask, y.g,
-                           (const double*)sums, x.g, B, C, SS);
+        hipLaunchKernelGGL(k_vt_bn_bwd_red, dim3(C, ch.n), dim3(kT), 0, st, x.v, mean, rstd, gamma, beta, mask, y.g,
+                           part2, B, C, SS, ch.per);
+        hipLaunchKernelGGL(k_vt_bn_bwd_x, dim3(nblk(x.n)), dim3(kT), 0, st, x.v, mean, rstd, gamma, beta, mask, y.g,
+                           (const double*)part2, ch.n, gg, gb, x.g, B, C, SS);
     });
     return y;
 }
@@ -623,16 +921,16 @@ Tn pool(VisTrain& v, const Tn& x) {
     const int S = x.s, So = (S - 1) / 2 + 1, BC = v.B * x.c;
     Tn y = v.tensor(x.c, So);
     VT_LAUNCH(v, k_vt_pool_fwd, nblk(y.n), x.v, y.v, BC, S, So);
-    VisTrain* pv = &v;
-    v.back([=] { hipLaunchKernelGGL(k_vt_pool_bwd, dim3(nblk(x.n)), dim3(kT), 0, pv->st, y.g, x.g, BC, S, So); });
+    const hipStream_t st = v.st;
+    v.back([=] { hipLaunchKernelGGL(k_vt_pool_bwd, dim3(nblk(x.n)), dim3(kT), 0, st, y.g, x.g, BC, S, So); });
     return y;
 }
 
 Tn relu(VisTrain& v, const Tn& x) {
     Tn y = v.tensor(x.c, x.s);
     VT_LAUNCH(v, k_vt_relu_fwd, nblk(y.n), x.v, y.v, y.n);
-    VisTrain* pv = &v;
-    v.back([=] { hipLaunchKernelGGL(k_vt_relu_bwd, dim3(nblk(x.n)), dim3(kT), 0, pv->st, x.v, y.g, x.g, x.n); });
+    const hipStream_t st = v.st;
+    v.back([=] { hipLaunchKernelGGL(k_vt_relu_bwd, dim3(nblk(x.n)), dim3(kT), 0, st, x.v, y.g, x.g, x.n); });
     return y;
 }
 
@@ -643,37 +941,63 @@ Tn conv1(VisTrain& v, const Tn& x, size_t w_off, size_t b_off, int Ci, int Co) {
     const float* w = v.blob + w_off;
     VT_LAUNCH(v, k_vt_conv1_fwd, nblk(y.n), x.v, w, v.blob + b_off, y.v, B, Ci, Co);
     float* gw = v.gw + w_off;
-    float* gb = v.gw + b_off;
-    VisTrain* pv = &v;
+    const int items = Co * Ci + Co; /* the bias follows its weight in the blob: one contiguous run of slots */
+    if (b_off != w_off + (size_t)Co * Ci) abort();
+    const Chunks ch = chunks_of((size_t)B * kS4);
+    double* part = v.no_grad ? nullptr : reinterpret_cast<double*>(v.scratch(2 * (size_t)items * ch.n));
+    const hipStream_t st = v.st;
     v.back([=] {
-        hipLaunchKernelGGL(k_vt_conv1_bwd_w, dim3(Co * Ci + Co), dim3(kT), 0, pv->st, x.v, y.g, gw, gb, B, Ci, Co);
-        hipLaunchKernelGGL(k_vt_conv1_bwd_x, dim3(nblk(x.n)), dim3(kT), 0, pv->st, y.g, w, x.g, B, Ci, Co);
+        hipLaunchKernelGGL(k_vt_conv1_bwd_w, dim3(items, ch.n), dim3(kT), 0, st, x.v, y.g, part, gw, B, Ci, Co, ch.per);
+        hipLaunchKernelGGL(k_vt_conv1_bwd_x, dim3(nblk(x.n)), dim3(kT), 0, st, y.g, w, x.g, B, Ci, Co,
+                           ch.n > 1 ? (const double*)part : nullptr, ch.n, gw);
     });
     return y;
 }
 
-Tn linear(VisTrain& v, const Tn& x, size_t w_off, size_t b_off, int N, int K, bool act) {
+Tn linear(VisTrain& v, const Tn& x, size_t w_off, size_t b_off, size_t q_off, int N, int K, bool act) {
     const int B = v.B;
     Tn y = v.tensor(N, 1);
     const float* W = v.blob + w_off;
-    VT_LAUNCH(v, k_vt_linear_fwd, nblk(y.n), x.v, W, v.blob + b_off, y.v, B, N, K, act ? 1 : 0);
+    VT_LAUNCH(v, k_vt_linear_fwd, nblk(y.n), x.v, v.quads + q_off, v.blob + b_off, y.v, B, N, K, act ? 1 : 0);
     float* gw = v.gw + w_off;
-    float* gb = v.gw + b_off;
-    VisTrain* pv = &v;
+    const int items = N * K + N; /* the bias follows its weight in the blob */
+    if (b_off != w_off + (size_t)N * K) abort();
+    const Chunks ch = chunks_of((size_t)B, 8);
+    double* part = v.no_grad ? nullptr : reinterpret_cast<double*>(v.scratch(2 * (size_t)items * ch.n));
+    const hipStream_t st = v.st;
+    const int relu = act ? 1 : 0;
     v.back([=] {
-        hipStream_t st = pv->st;
-        if (act) hipLaunchKernelGGL(k_vt_relu_mask, dim3(nblk(y.n)), dim3(kT), 0, st, y.g, y.v, y.n);
-        hipLaunchKernelGGL(k_vt_linear_bwd_w, dim3(nblk((size_t)N * K + N)), dim3(kT), 0, st, x.v, y.g, gw, gb, B, N, K);
-        hipLaunchKernelGGL(k_vt_linear_bwd_x, dim3(nblk(x.n)), dim3(kT), 0, st, y.g, W, x.g, B, N, K);
+        hipLaunchKernelGGL(k_vt_linear_bwd_w, dim3(nblk(items), ch.n), dim3(kT), 0, st, x.v, y.g, y.v, part, gw, B, N, K,
+                           (int)ch.per, relu);
+        if (ch.n > 1)
+            hipLaunchKernelGGL(k_vt_accum_fin, dim3((items + 3) / 4), dim3(kT), 0, st, (const double*)part, items, ch.n, gw);
+        hipLaunchKernelGGL(k_vt_linear_bwd_x, dim3(nblk(x.n)), dim3(kT), 0, st, y.g, y.v, W, x.g, B, N, K, relu);
     });
     return y;
 }
 
-Tn mlp(VisTrain& v, const Tn& x, const mzs_vis_mlp& m) {
+/* the Linear layers' copies in the search kernels' quad store (mzs_vision.h vis_lin_offsets: head after head —
+ * 0 reward, 1 value, 2 policy — in, mid, out, each from a multiple of four floats) */
+struct QuadOff {
+    size_t in_w, mid_w, out_w;
+};
+QuadOff quad_offsets(const mzs_dims& d, int head) {
+    const auto r4 = [](size_t n) { return (n + 3) & ~(size_t)3; };
+    const size_t H = (size_t)d.hidden_dim, Sd = (size_t)d.state_dim;
+    const size_t head_sd = r4(H * kHid) + r4(H * H) + r4(Sd * H); /* heads 0 and 1 both end in Sd outputs */
+    QuadOff q;
+    q.in_w = (size_t)head * head_sd;
+    q.mid_w = q.in_w + r4(H * kHid);
+    q.out_w = q.mid_w + r4(H * H);
+    return q;
+}
+
+Tn mlp(VisTrain& v, const Tn& x, const mzs_vis_mlp& m, int head) {
     const int H = v.d.hidden_dim;
-    Tn y = linear(v, x, m.in_w, m.in_b, H, kHid, true);
-    for (int l = 0; l < v.d.n_mid_layers; ++l) y = linear(v, y, m.mid_w, m.mid_b, H, H, true);
-    return linear(v, y, m.out_w, m.out_b, m.n_out, H, false);
+    const QuadOff q = quad_offsets(v.d, head);
+    Tn y = linear(v, x, m.in_w, m.in_b, q.in_w, H, kHid, true);
+    for (int l = 0; l < v.d.n_mid_layers; ++l) y = linear(v, y, m.mid_w, m.mid_b, q.mid_w, H, H, true);
+    return linear(v, y, m.out_w, m.out_b, q.out_w, m.n_out, H, false);
 }
 
 Tn representation(VisTrain& v, const float* obs) {
@@ -695,8 +1019,8 @@ void prediction(VisTrain& v, const Tn& h, Tn* pol, Tn* val) {
     const mzs_vision_offsets& o = v.o;
     Tn x = h;
     for (int l = 0; l < v.d.n_mid_layers; ++l) x = res_block(v, x, o.p_res);
-    *val = mlp(v, conv1(v, x, o.p_conv_val, o.p_conv_val_b, MZS_VIS_C, MZS_VIS_C), o.p_v);
-    *pol = mlp(v, conv1(v, x, o.p_conv_pol, o.p_conv_pol_b, MZS_VIS_C, MZS_VIS_C), o.p_p);
+    *val = mlp(v, conv1(v, x, o.p_conv_val, o.p_conv_val_b, MZS_VIS_C, MZS_VIS_C), o.p_v, 1);
+    *pol = mlp(v, conv1(v, x, o.p_conv_pol, o.p_conv_pol_b, MZS_VIS_C, MZS_VIS_C), o.p_p, 2);
 }
 
 void dynamics(VisTrain& v, const Tn& h, const float* actions_k, Tn* rew, Tn* next) {
@@ -704,22 +1028,38 @@ void dynamics(VisTrain& v, const Tn& h, const float* actions_k, Tn* rew, Tn* nex
     const int B = v.B;
     Tn x = v.tensor(MZS_VIS_C + 1, MZS_VIS_S4);
     VT_LAUNCH(v, k_vt_cat_fwd, nblk(x.n), h.v, actions_k, x.v, B, v.d.n_actions);
-    VisTrain* pv = &v;
-    v.back([=] { hipLaunchKernelGGL(k_vt_cat_bwd, dim3(nblk(h.n)), dim3(kT), 0, pv->st, x.g, h.g, B); });
+    const hipStream_t st = v.st;
+    v.back([=] { hipLaunchKernelGGL(k_vt_cat_bwd, dim3(nblk(h.n)), dim3(kT), 0, st, x.g, h.g, B); });
     Tn y = bn_act(v, conv3(v, x, o.d_conv, MZS_VIS_C + 1, MZS_VIS_C, 1, nullptr), o.d_bn, false);
     for (int l = 0; l < v.d.n_mid_layers; ++l) y = res_block(v, y, o.d_res);
     *next = relu(v, y);
-    *rew = mlp(v, conv1(v, x, o.d_conv_rew, o.d_conv_rew_b, MZS_VIS_C + 1, MZS_VIS_C), o.d_fc);
+    *rew = mlp(v, conv1(v, x, o.d_conv_rew, o.d_conv_rew_b, MZS_VIS_C + 1, MZS_VIS_C), o.d_fc, 0);
 }
 
-/* Builds (and unless vt.dry, launches) one training step; returns the floats of arena it used. */
+/* a prediction pass on the side stream: it reads the hidden state h through an alias with a gradient buffer of
+ * its own (its backward pass runs beside the dynamics chain's, which adds to h.g too) */
+void prediction_beside(VisTrain& v, const Tn& h, Tn* pol, Tn* val) {
+    Tn hp = v.tensor(h.c, h.s);
+    hp.v = h.v;
+    const hipStream_t main_st = v.main_st;
+    v.back([=] { hipLaunchKernelGGL(k_vt_axpy, dim3(nblk(h.n)), dim3(kT), 0, main_st, h.g, hp.g, 1.0f, h.n); });
+    v.link(v.main_st, v.side);
+    v.st = v.side;
+    prediction(v, hp, pol, val);
+    v.st = v.main_st;
+}
+
+/* Builds (and unless vt.dry, launches) one training step.  Two streams: the representation and the dynamics chain
+ * on the caller's, the K + 1 prediction passes on a side stream (a prediction hangs off the chain: nothing but the
+ * losses waits for it) — forward and backward. */
 void build_step(VisTrain& v, const float* obs, LossParams* lp) {
-    v.used = 0, v.mask_pos = 0, v.no_grad = false;
+    v.used = 0, v.mask_pos = 0, v.no_grad = false, v.n_events = 0;
     v.tape.clear();
+    v.st = v.main_st;
     const int K = v.K;
     Tn h = representation(v, obs);
     Tn pol, val, rew, nh;
-    prediction(v, h, &pol, &val);
+    prediction_beside(v, h, &pol, &val);
     lp->val[0] = val.v, lp->pol[0] = pol.v, lp->rew[0] = nullptr;
     lp->gval[0] = val.g, lp->gpol[0] = pol.g, lp->grew[0] = nullptr;
     for (int k = 0; k < K; ++k) {
@@ -731,16 +1071,17 @@ void build_step(VisTrain& v, const float* obs, LossParams* lp) {
          * at it — from the prediction and from the next dynamics step — is halved on its way into this one */
         Tn hs = v.tensor(nh.c, nh.s);
         hs.v = nh.v;
-        VisTrain* pv = &v;
-        v.back([=] { hipLaunchKernelGGL(k_vt_axpy, dim3(nblk(nh.n)), dim3(kT), 0, pv->st, nh.g, hs.g, 0.5f, nh.n); });
+        const hipStream_t st = v.st;
+        v.back([=] { hipLaunchKernelGGL(k_vt_axpy, dim3(nblk(nh.n)), dim3(kT), 0, st, nh.g, hs.g, 0.5f, nh.n); });
         h = hs;
-        prediction(v, h, &pol, &val);
+        prediction_beside(v, h, &pol, &val);
         if (k + 1 < K) {
             lp->val[k + 1] = val.v, lp->pol[k + 1] = pol.v, lp->rew[k + 1] = rew.v;
             lp->gval[k + 1] = val.g, lp->gpol[k + 1] = pol.g, lp->grew[k + 1] = rew.g;
         }
     }
     v.no_grad = false;
+    v.link(v.side, v.main_st); /* the losses wait for the predictions; the predictions' backward passes for the losses */
 }
 
 std::vector<unsigned char> l2_flags(const mzs_dims& d, const mzs_vision_offsets& o) {
@@ -836,6 +1177,7 @@ int vis_train_create(VisTrain** out, const mzs_dims& d, int max_batch, int K, in
         (e = alloc((void**)&v->grads, v->arena * sizeof(float))) != hipSuccess ||
         (e = alloc((void**)&v->stat, v->n_params * sizeof(float))) != hipSuccess ||
         (e = alloc((void**)&v->loss_buf, (size_t)max_batch * (3 * K) * sizeof(float))) != hipSuccess ||
+        (e = alloc((void**)&v->sq_part, (size_t)nblk(v->n_params) * sizeof(double))) != hipSuccess ||
         (e = alloc((void**)&v->stat_flag, v->n_params)) != hipSuccess ||
         (e = alloc((void**)&v->l2_flag, v->n_params)) != hipSuccess ||
         (e = alloc((void**)&v->own_masks, v->own_masks_n)) != hipSuccess ||
@@ -845,12 +1187,22 @@ int vis_train_create(VisTrain** out, const mzs_dims& d, int max_batch, int K, in
         vis_train_destroy(v);
         return vt_fail(err, msg);
     }
+    if ((e = hipStreamCreateWithFlags(&v->side, hipStreamNonBlocking)) != hipSuccess) {
+        const std::string msg = std::string("vision training side stream: ") + hipGetErrorString(e);
+        vis_train_destroy(v);
+        return vt_fail(err, msg);
+    }
     *out = v;
     return MZS_OK;
 }
 
 void vis_train_destroy(VisTrain* v) {
     if (!v) return;
+    if (v->side) {
+        (void)hipStreamSynchronize(v->side);
+        (void)hipStreamDestroy(v->side);
+    }
+    for (hipEvent_t e : v->events) (void)hipEventDestroy(e);
     for (void* p : v->allocs) (void)hipFree(p);
     delete v;
 }
@@ -864,13 +1216,15 @@ int64_t vis_train_mask_count(VisTrain* v, int batch) {
 
 const unsigned char* vis_train_stat_flags(const VisTrain* v) { return v->stat_flag; }
 
-int vis_train_grad(VisTrain* v, const float* blob_dev, int batch, const float* obs_dev, const float* actions_dev,
+int vis_train_grad(VisTrain* v, const float* blob_dev, const float* quad_store_dev, int batch, const float* obs_dev, const float* actions_dev,
                    const float* tv_dev, const float* tr_dev, const float* tp_dev, const float* is_ratio_dev,
                    float inv_global_batch, int loss_value, int loss_reward, const unsigned char* masks_dev,
                    uint64_t seed, uint64_t step, float* grad_dev, float* loss_dev, float* priority_dev,
                    hipStream_t st, std::string* err) {
     const int K = v->K;
-    v->dry = false, v->B = batch, v->st = st, v->blob = blob_dev, v->gw = grad_dev, v->actions = actions_dev;
+    v->dry = false, v->B = batch, v->st = st, v->main_st = st, v->blob = blob_dev, v->gw = grad_dev;
+    v->actions = actions_dev;
+    v->quads = quad_store_dev;
     if (!masks_dev) {
         const size_t n = (size_t)vis_train_mask_count(v, batch);
         v->dry = false, v->B = batch;
@@ -897,6 +1251,9 @@ int vis_train_grad(VisTrain* v, const float* blob_dev, int batch, const float* o
     fp.is_ratio = is_ratio_dev, fp.loss_buf = v->loss_buf, fp.grad = grad_dev, fp.loss_out = loss_dev;
     fp.n_params = (int)v->n_params, fp.B = batch, fp.K = K, fp.inv_batch = inv_global_batch;
     const int ngb = (int)nblk(v->n_params);
+    fp.sq_part = v->sq_part;
+    hipLaunchKernelGGL(k_vt_l2sq, dim3(ngb), dim3(kT), 0, st, blob_dev, (const unsigned char*)v->l2_flag, (int)v->n_params,
+                       v->sq_part);
     hipLaunchKernelGGL(k_vt_finalize, dim3(ngb + 1), dim3(kT), 0, st, fp, ngb);
     VT_TRY(hipGetLastError());
     return MZS_OK;

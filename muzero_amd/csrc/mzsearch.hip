@@ -2133,7 +2133,7 @@ int mzs_train_grad(mzs_handle* h, int32_t batch, const float* obs_dev, const flo
         }
         h->dropout_masks = nullptr; /* injected masks serve one call */
         std::string err;
-        const int rc = vis_train_grad(h->vis_train, h->blob_dev, batch, obs_dev, actions_dev, target_value_dev,
+        const int rc = vis_train_grad(h->vis_train, h->blob_dev, h->w_dev, batch, obs_dev, actions_dev, target_value_dev,
                                       target_reward_dev, target_policy_dev, is_ratio_dev, inv_global_batch,
                                       h->loss_value, h->loss_reward, masks, h->dropout_seed, h->train_calls++, grad_dev,
                                       loss_dev, priority_dev, static_cast<hipStream_t>(stream), &err);
