@@ -166,3 +166,65 @@ def test_vision_muzero_train_drop_in():
     assert loss < first
     res = Monte_carlo_tree_search(discount=0.997).run_batch(kw["obs"][:3], 6, mz, True, seeds=np.arange(3))
     assert np.all(res.policy.sum(axis=1) == 6)
+
+
+def random_vision_blob(rs, A, Sd, H, L):
+    parts = []
+    for name, shape in vo.blob_layout(A, Sd, H, L):
+        n = int(np.prod(shape))
+        if name.endswith("_var"):
+            v = 0.5 + rs.uniform(size=n)
+        elif name.endswith("_mean"):
+            v = 0.3 * rs.standard_normal(n)
+        elif name.endswith("bn_w"):
+            v = 0.5 + rs.uniform(size=n)
+        elif name.endswith(("_b", "bn_b")):
+            v = 0.1 * rs.standard_normal(n)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            v = rs.standard_normal(n) * (1.3 / np.sqrt(fan_in))
+        parts.append(v.astype(np.float32))
+    return np.concatenate(parts)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_vision_training_random_shapes_vs_oracle(seed):
+    """Random head shapes, unroll lengths (K = 1: only forward-only dynamics), batch sizes (B = 1: batch statistics
+    of one sample), the four loss types, with and without importance weights, absorbing actions — one step against
+    the oracle, masks drawn here and injected into both."""
+    from muzero_amd.engine import SearchEngine
+    from muzero_amd.train import LOSS_TYPES, Trainer
+    rs = np.random.RandomState(1000 + seed)
+    A, Sd, H, L = int(rs.randint(2, 7)), int(rs.randint(3, 32)), int(rs.choice([8, 12, 33, 64])), int(rs.randint(1, 3))
+    K, B = (1, 5) if seed == 0 else (int(rs.randint(2, 5)), 1 if seed == 1 else int(rs.randint(2, 11)))
+    loss_type = ["general", "general", "game_mmc", "game", "general_kkc", "general"][seed]
+    blob = random_vision_blob(rs, A, Sd, H, L)
+    obs = rs.uniform(0.0, 1.0, size=(B, 3, 98, 98)).astype(np.float32)
+    actions = np.zeros((K, B, A), np.float32)
+    actions[np.arange(K)[:, None], np.arange(B)[None, :], rs.randint(0, A, size=(K, B))] = 1.0
+    actions[K - 1:, 0] = 0.0                                                      # an absorbing tail
+    tv = rs.uniform(0.0 if loss_type == "general_kkc" else -3.0, 10.0, size=(K, B)).astype(np.float32)
+    tr = rs.choice([0.0, 1.0, 2.5], size=(K, B)).astype(np.float32)
+    tpol = rs.dirichlet([0.7] * A, size=(K, B)).astype(np.float32)
+    isr = rs.uniform(0.3, 1.4, size=B).astype(np.float32) if seed % 2 else None
+    eng = SearchEngine((98, A, Sd, H, L, 2), max_games=1, max_simulations=0)
+    eng.set_weights(blob)
+    tr_ = Trainer(eng, K, B + (seed % 3), "adam", 0.01, loss_type=loss_type)
+    masks = (rs.uniform(size=tr_.dropout_count(B)) < 0.5).astype(np.uint8)
+    tr_.set_dropout(masks)
+    prio = tr_.step(obs, actions, tv, tr, tpol, isr)
+    import torch
+    torch.cuda.synchronize()
+    lv, lr_ = LOSS_TYPES[loss_type]
+    want = vo.train_grad(blob, (98, A, Sd, H, L), K, obs, actions, tv, tr, tpol, isr, masks, loss_value=lv,
+                         loss_reward=lr_)
+    got_loss = tr_.loss.cpu().numpy().astype(np.float64)
+    assert np.abs(got_loss - want["losses"]).max() <= 1e-5 * max(1.0, np.abs(want["losses"]).max())
+    assert priority_close(prio.cpu().numpy().astype(np.float64), want["priority"], tv)
+    stat = vo.Optimizer("adam", blob.size, (98, A, Sd, H, L)).is_stat
+    g = tr_.grad.cpu().numpy().astype(np.float64)
+    assert np.abs(blob[stat] + g[stat] - want["running"][stat]).max() <= 5e-6
+    g[stat] = 0.0
+    # MSE criteria differentiate through softmax probabilities near 0/1: same bound, seen 1e-6
+    check_grad((98, A, Sd, H, L), g, want["grad"], f"seed {seed} ({loss_type}, A {A} Sd {Sd} H {H} L {L} K {K} B {B})")
+    eng.close()
