@@ -217,7 +217,7 @@ int mzs_train_grad(mzs_handle* h, int32_t batch, const float* obs_dev, const flo
  * mzs_train_create and calls no hipMalloc / hipFree / allocating routine: tapes, per-sample loss
  * terms and gradient partial sums live in a file-scope static device array of
  * MZS_STATIC_SCRATCH_BYTES (16 MiB) that every GPU the library runs on holds until the process
- * ends.  Sizes beyond it (e.g. the CartPole MLP at unroll 5 fits batch <= ~900) return MZS_E_ARG.
+ * ends.  Sizes beyond it (e.g. the CartPole MLP at unroll 5 fits batch <= 777) return MZS_E_ARG.
  * Every call on a GPU shares that GPU's array: calls that overlap on one GPU (two streams, two
  * handles, two threads) race — serialise them.  The handle still comes from mzs_create +
  * mzs_set_weights (which allocate, once, outside the loop). */

@@ -297,7 +297,7 @@ __global__ void __launch_bounds__(64) k_train_sample(const TrainParams p) {
     for (int i = lane; i < t.copy_n; i += kWave) dst[i] = T[i];
 }
 
-constexpr int kWgradChunk = 8; /* samples per partial sum */
+constexpr int kWgradChunk = 16; /* samples per partial sum */
 
 /* Weight gradients, pass 1: thread (blob element i, sample chunk c) = sum over the chunk's
  * samples and every use of the tensor of delta[n] * x[k]  ->  partial[c][i].  Fixed order, no
@@ -318,27 +318,60 @@ __global__ void __launch_bounds__(256) k_train_wgrad_partial(const TrainParams p
     const TensorDesc d = p.td[ti];
     const int b0 = blockIdx.y * kWgradChunk, b1 = min(b0 + kWgradChunk, p.B);
     double acc = 0.0;
-    for (int b = b0; b < b1; ++b) {
-        const float* tape = p.tape + (size_t)b * p.tl.copy_n;
-        for (int u = 0; u < d.outer_n; ++u)
-            for (int v = 0; v < d.inner_n; ++v) {
-                const float dl = tape[d.d_off + u * d.outer_stride + v * d.inner_sd + n];
-                const float x = kk < 0 ? 1.0f : tape[d.x_off + u * d.outer_stride + v * d.inner_sx + kk];
-                acc += (double)dl * (double)x;
+    /* per use of the tensor, the chunk's sixteen samples are requested together (the loop waited out one trip to
+     * L2 / HBM per product before); a missing sample of the last chunk reads sample b1 - 1 and adds nothing */
+    for (int u = 0; u < d.outer_n; ++u)
+        for (int v = 0; v < d.inner_n; ++v) {
+            const int doff = d.d_off + u * d.outer_stride + v * d.inner_sd + n;
+            const int xoff = d.x_off + u * d.outer_stride + v * d.inner_sx + (kk < 0 ? 0 : kk);
+            float dl[kWgradChunk], x[kWgradChunk];
+#pragma unroll
+            for (int s = 0; s < kWgradChunk; ++s) {
+                const float* tape = p.tape + (size_t)min(b0 + s, b1 - 1) * p.tl.copy_n;
+                dl[s] = tape[doff];
+                x[s] = tape[xoff];
             }
-    }
+#pragma unroll
+            for (int s = 0; s < kWgradChunk; ++s)
+                if (b0 + s < b1) acc += (double)dl[s] * (kk < 0 ? 1.0 : (double)x[s]);
+        }
     partial[(size_t)blockIdx.y * p.n_params + i] = acc;
 }
 
-/* pass 2: sum the chunk partials in order (+ l2); the last block reduces the loss terms */
+/* pass 2: sum the chunk partials (+ l2); the last block reduces the loss terms.  A gradient block = 64
+ * parameters x 4 groups of chunks (group g: chunks g, g + 4, ..., eight requested at a time), the groups added
+ * in order through LDS: a fixed summation order with 32 x fewer dependent trips to memory than one thread per
+ * parameter walking all chunks. */
+constexpr int kWgradParams = 64; /* parameters per block of k_train_wgrad */
 __global__ void __launch_bounds__(256) k_train_wgrad(const TrainParams p, const double* partial,
                                                      int n_chunks, int n_grad_blocks) {
     const int K = p.K, B = p.B, n_terms = 3 * K - 1;
+    __shared__ double red[256];
     if ((int)blockIdx.x < n_grad_blocks) {
-        const int i = blockIdx.x * blockDim.x + threadIdx.x;
-        if (i >= p.n_params) return;
-        double acc = 0.0;
-        for (int c = 0; c < n_chunks; ++c) acc += partial[(size_t)c * p.n_params + i];
+        const int i = blockIdx.x * kWgradParams + (threadIdx.x & (kWgradParams - 1)), g = threadIdx.x / kWgradParams;
+        const int ii = min(i, p.n_params - 1);
+        double part = 0.0;
+        for (int c0 = g; c0 < n_chunks; c0 += 4 * 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int c = c0 + 4 * u;
+                v[u] = c < n_chunks ? partial[(size_t)c * p.n_params + ii] : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) part += v[u];
+        }
+        /* the batch's total sample weight (the l2 term's factor): the samples spread over the block's threads */
+        __shared__ double wsum_s[4];
+        double wpart = 0.0;
+        for (int b = threadIdx.x; b < B; b += blockDim.x) wpart += (double)((p.is_ratio ? p.is_ratio[b] : 1.0f) * p.inv_batch);
+        for (int off = kWave / 2; off > 0; off >>= 1) wpart += __shfl_down(wpart, off, kWave);
+        if ((threadIdx.x & (kWave - 1)) == 0) wsum_s[threadIdx.x / kWave] = wpart;
+        red[threadIdx.x] = part;
+        __syncthreads();
+        if (g != 0 || i >= p.n_params) return;
+        double acc = ((red[threadIdx.x] + red[threadIdx.x + kWgradParams]) + red[threadIdx.x + 2 * kWgradParams]) +
+                     red[threadIdx.x + 3 * kWgradParams];
         int l2 = 0;
         for (int q = 0; q < kTrainTensors; ++q) {
             const TensorDesc& d = p.td[q];
@@ -346,19 +379,18 @@ __global__ void __launch_bounds__(256) k_train_wgrad(const TrainParams p, const 
                 l2 = d.l2;
         }
         if (l2) {
-            double wsum = 0.0;
-            for (int b = 0; b < B; ++b) wsum += (double)((p.is_ratio ? p.is_ratio[b] : 1.0f) * p.inv_batch);
+            const double wsum = ((wsum_s[0] + wsum_s[1]) + wsum_s[2]) + wsum_s[3];
             acc += 2.0 * 1e-4 * wsum * (double)p.blob[i];
         }
         p.grad[i] = (float)acc;
         return;
     }
     /* loss block: batch means of the raw terms (muzero_model.py:603) and loss_nn (:725-734) */
-    __shared__ double red[256];
     double sq = 0.0;
     for (int q = 0; q < kTrainTensors; ++q) {
         const TensorDesc& d = p.td[q];
         if (!d.l2) continue;
+#pragma unroll 8
         for (int i = threadIdx.x; i < d.n_out * d.n_in; i += blockDim.x) sq += (double)p.blob[d.w_off + i] * p.blob[d.w_off + i];
         for (int i = threadIdx.x; i < d.n_out; i += blockDim.x) sq += (double)p.blob[d.b_off + i] * p.blob[d.b_off + i];
     }
@@ -384,12 +416,15 @@ __global__ void __launch_bounds__(256) k_train_wgrad(const TrainParams p, const 
     sq = block_sum(sq);
     tot = block_sum(tot);
     wsum = block_sum(wsum);
-    for (int q = threadIdx.x; q < n_terms; q += blockDim.x) {
-        double s = 0.0;
-        for (int b = 0; b < B; ++b) s += (double)p.loss_buf[(size_t)b * n_terms + q];
-        p.loss_out[q] = (float)(s * (double)p.inv_batch);
-    }
     if (threadIdx.x == 0) p.loss_out[n_terms] = (float)(tot + wsum * 1e-4 * sq);
+    /* a term's batch mean: one wavefront per term, a lane per sample, a fixed shuffle tree */
+    const int lane = threadIdx.x & (kWave - 1);
+    for (int q = threadIdx.x / kWave; q < n_terms; q += blockDim.x / kWave) {
+        double s = 0.0;
+        for (int b = lane; b < B; b += kWave) s += (double)p.loss_buf[(size_t)b * n_terms + q];
+        for (int off = kWave / 2; off > 0; off >>= 1) s += __shfl_down(s, off, kWave);
+        if (lane == 0) p.loss_out[q] = (float)(s * (double)p.inv_batch);
+    }
 }
 
 struct ApplyParams {

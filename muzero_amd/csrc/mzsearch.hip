@@ -2105,8 +2105,9 @@ static int train_grad_launch(mzs_handle* h, const TapeLayout& tl, int K, int32_t
     const int n_chunks = (batch + kWgradChunk - 1) / kWgradChunk;
     hipLaunchKernelGGL(k_train_wgrad_partial, dim3(n_grad_blocks, n_chunks), dim3(256), 0, st, p, partial);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(k_train_wgrad, dim3(n_grad_blocks + 1), dim3(256), 0, st, p, (const double*)partial, n_chunks,
-                       n_grad_blocks);
+    const int n_sum_blocks = (p.n_params + kWgradParams - 1) / kWgradParams;
+    hipLaunchKernelGGL(k_train_wgrad, dim3(n_sum_blocks + 1), dim3(256), 0, st, p, (const double*)partial, n_chunks,
+                       n_sum_blocks);
     HIP_TRY(hipGetLastError());
     return MZS_OK;
 }
