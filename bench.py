@@ -243,7 +243,7 @@ def main():
                                          "frac": ach / HBM_PEAK_GBS, "bytes_per_sim": bps},
                            "note": "neither roofline binds at this model size: one wave per SIMD, "
                                    "instruction issue 63 % / LDS and memory waits 31 % of wave cycles "
-                                   "(profiles/r2c_quad_summary.md, DESIGN.md 4)"}
+                                   "(profiles/r3_quad_summary.md, DESIGN.md 4)"}
         if world == 1 and not args.no_cpu_baseline and args.dtype == "f32":
             out["cpu_baseline"] = cpu_baseline(dims[:6], w["blob"], S, eng.pbc)
         print(json.dumps(out), flush=True)
