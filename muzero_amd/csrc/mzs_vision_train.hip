@@ -23,7 +23,6 @@
  */
 #include "mzs_vision_train.h"
 
-#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <vector>
@@ -816,10 +815,14 @@ struct VisTrain {
     void back(std::function<void()> fn) {
         if (!dry && !no_grad) tape.push_back(std::move(fn));
     }
+    const char* failed = nullptr; /* first internal failure of the step being built (vis_train_grad reports it) */
     hipEvent_t event() {
         if (n_events == events.size()) {
-            hipEvent_t e;
-            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) abort();
+            hipEvent_t e = nullptr;
+            if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+                failed = "hipEventCreateWithFlags failed";
+                return nullptr;
+            }
             events.push_back(e);
         }
         return events[n_events++];
@@ -829,10 +832,12 @@ struct VisTrain {
     void link(hipStream_t from, hipStream_t to) {
         if (dry || from == to) return;
         hipEvent_t e = event();
+        if (!e) return;
         (void)hipEventRecord(e, from);
         (void)hipStreamWaitEvent(to, e, 0);
         if (no_grad) return;
         hipEvent_t r = event();
+        if (!r) return;
         tape.push_back([=] {
             (void)hipEventRecord(r, to);
             (void)hipStreamWaitEvent(from, r, 0);
@@ -942,7 +947,7 @@ Tn conv1(VisTrain& v, const Tn& x, size_t w_off, size_t b_off, int Ci, int Co) {
     VT_LAUNCH(v, k_vt_conv1_fwd, nblk(y.n), x.v, w, v.blob + b_off, y.v, B, Ci, Co);
     float* gw = v.gw + w_off;
     const int items = Co * Ci + Co; /* the bias follows its weight in the blob: one contiguous run of slots */
-    if (b_off != w_off + (size_t)Co * Ci) abort();
+    if (b_off != w_off + (size_t)Co * Ci) v.failed = "blob layout: a 1 x 1 convolution's bias does not follow its weight";
     const Chunks ch = chunks_of((size_t)B * kS4);
     double* part = v.no_grad ? nullptr : reinterpret_cast<double*>(v.scratch(2 * (size_t)items * ch.n));
     const hipStream_t st = v.st;
@@ -961,7 +966,7 @@ Tn linear(VisTrain& v, const Tn& x, size_t w_off, size_t b_off, size_t q_off, in
     VT_LAUNCH(v, k_vt_linear_fwd, nblk(y.n), x.v, v.quads + q_off, v.blob + b_off, y.v, B, N, K, act ? 1 : 0);
     float* gw = v.gw + w_off;
     const int items = N * K + N; /* the bias follows its weight in the blob */
-    if (b_off != w_off + (size_t)N * K) abort();
+    if (b_off != w_off + (size_t)N * K) v.failed = "blob layout: a Linear layer's bias does not follow its weight";
     const Chunks ch = chunks_of((size_t)B, 8);
     double* part = v.no_grad ? nullptr : reinterpret_cast<double*>(v.scratch(2 * (size_t)items * ch.n));
     const hipStream_t st = v.st;
@@ -1054,6 +1059,7 @@ void prediction_beside(VisTrain& v, const Tn& h, Tn* pol, Tn* val) {
  * losses waits for it) — forward and backward. */
 void build_step(VisTrain& v, const float* obs, LossParams* lp) {
     v.used = 0, v.mask_pos = 0, v.no_grad = false, v.n_events = 0;
+    v.failed = nullptr;
     v.tape.clear();
     v.st = v.main_st;
     const int K = v.K;
@@ -1155,6 +1161,11 @@ int vis_train_create(VisTrain** out, const mzs_dims& d, int max_batch, int K, in
     v->dry = true, v->B = max_batch;
     LossParams lp;
     build_step(*v, nullptr, &lp);
+    if (v->failed) {
+        if (err) *err = v->failed;
+        delete v;
+        return MZS_E_ARG;
+    }
     v->arena = v->used;
     v->own_masks_n = v->mask_pos;
     const auto alloc = [&](void** p, size_t bytes) {
@@ -1222,13 +1233,16 @@ int vis_train_grad(VisTrain* v, const float* blob_dev, const float* quad_store_d
                    uint64_t seed, uint64_t step, float* grad_dev, float* loss_dev, float* priority_dev,
                    hipStream_t st, std::string* err) {
     const int K = v->K;
-    v->dry = false, v->B = batch, v->st = st, v->main_st = st, v->blob = blob_dev, v->gw = grad_dev;
+    v->st = st, v->main_st = st, v->blob = blob_dev, v->gw = grad_dev;
     v->actions = actions_dev;
     v->quads = quad_store_dev;
+    /* a dry pass first: the step's arena use and mask count, checked before anything is launched */
+    const size_t n_masks = (size_t)vis_train_mask_count(v, batch);
+    if (v->failed) return vt_fail(err, v->failed);
+    if (v->used > v->arena || n_masks > v->own_masks_n) return vt_fail(err, "vision training arena too small (internal)");
+    v->dry = false, v->B = batch;
     if (!masks_dev) {
-        const size_t n = (size_t)vis_train_mask_count(v, batch);
-        v->dry = false, v->B = batch;
-        hipLaunchKernelGGL(k_vt_draw_masks, dim3(nblk(n)), dim3(kT), 0, st, v->own_masks, n, seed, step);
+        hipLaunchKernelGGL(k_vt_draw_masks, dim3(nblk(n_masks)), dim3(kT), 0, st, v->own_masks, n_masks, seed, step);
         masks_dev = v->own_masks;
     }
     v->masks = masks_dev;
@@ -1238,7 +1252,11 @@ int vis_train_grad(VisTrain* v, const float* blob_dev, const float* quad_store_d
     LossParams lp;
     std::memset(&lp, 0, sizeof lp);
     build_step(*v, obs_dev, &lp);
-    if (v->used > v->arena) return vt_fail(err, "vision training arena overrun (internal)");
+    if (v->failed) { /* launches already queued read only buffers this object owns; the step's outputs are undefined */
+        (void)hipStreamSynchronize(v->side);
+        v->tape.clear();
+        return vt_fail(err, v->failed);
+    }
     lp.tv = tv_dev, lp.tr = tr_dev, lp.tp = tp_dev, lp.is_ratio = is_ratio_dev;
     lp.loss_buf = v->loss_buf, lp.priority = priority_dev;
     lp.B = batch, lp.K = K, lp.S = v->d.state_dim, lp.A = v->d.n_actions;
