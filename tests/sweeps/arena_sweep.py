@@ -6,7 +6,7 @@ search results move by move, and compare: after every move the status entry (que
 observations, after every round all trajectory arrays of its rows, then Game.make_priority (padded and packed)
 and a random batch of make_target positions (mzs_arena_make_batch) — integer, fp32 and fp64 work, bit for bit.
 Test infrastructure like tests/.  Prints one JSON line per case and a summary; exits non-zero on a mismatch.
-Usage: python tools/arena_sweep.py [--seconds 60] [--seed 0]"""
+Usage: python tests/sweeps/arena_sweep.py [--seconds 60] [--seed 0]"""
 import argparse
 import json
 import os
@@ -15,7 +15,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

@@ -5,7 +5,7 @@ count, a simulation count and seeds; run the search through the C-ABI with devic
 streams — visit counts, root values, consumed draws, expansion order and every node's value sum, bit for
 bit.  Test infrastructure like tests/: the oracle is the checker, never the product path.
 Prints one JSON line per case and a summary line; exits non-zero on the first mismatch.
-Usage: python tools/parity_sweep.py [--seconds 120] [--seed 0] [--threads 16]"""
+Usage: python tests/sweeps/parity_sweep.py [--seconds 120] [--seed 0] [--threads 16]"""
 import argparse
 import json
 import os
@@ -14,7 +14,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 # (obs_dim, A, S_dim, H, L, kind): the shapes the specialised kernels exist for, and others that fall to the generic one

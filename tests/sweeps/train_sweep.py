@@ -7,7 +7,7 @@ with the CPU oracle's train_grad on the same inputs (fp32 tolerances of tests/te
 (A three-entry hidden state — S_dim 3 — was in the list once: its min-max normalisation is so ill-conditioned
 that rounding differences reached 3e-5 of the largest gradient entry after five unroll steps; replaced by S_dim 9.)
 Prints one JSON line per case and a summary; exits non-zero on the first case out of tolerance.
-Usage: python tools/train_sweep.py [--seconds 60] [--seed 0]"""
+Usage: python tests/sweeps/train_sweep.py [--seconds 60] [--seed 0]"""
 import argparse
 import json
 import os
@@ -16,7 +16,7 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 LOSS_REL, GRAD_REL = 1e-5, 1e-5

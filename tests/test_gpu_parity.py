@@ -378,13 +378,13 @@ def test_stream_kernel_shapes_vs_oracle(shape, G, S):
 
 
 def test_randomised_sweep_equals_oracle():
-    """A few seconds of tools/parity_sweep.py: random shapes (every specialised kernel and the generic
+    """A few seconds of tests/sweeps/parity_sweep.py: random shapes (every specialised kernel and the generic
     one, fp32 and bf16), weight scales, game and simulation counts, with and without root noise, short
     stream prefixes that force the device-side redo pass — every game == oracle, bit for bit.  The long
     runs are recorded in profiles/r2d_parity_sweep.md."""
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "sweeps"))
     import parity_sweep
     out = parity_sweep.run(8.0, seed=2024, threads=8, max_games=1024, log=lambda s: None)
     assert out["summary"] == "all equal", out

@@ -173,12 +173,12 @@ def test_large_arena_vs_oracle():
 
 
 def test_randomised_arena_sweep_equals_oracle():
-    """Eight seconds of tools/arena_sweep.py: random slot counts, episode limits, ragged round sizes, rolling
+    """Eight seconds of tests/sweeps/arena_sweep.py: random slot counts, episode limits, ragged round sizes, rolling
     rounds on a ring of rows, temperatures — status entries and observations after every move, trajectories,
     priorities and make_target batches after every round == the oracle's (profiles/r2d_arena_sweep.md)."""
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "sweeps"))
     import arena_sweep
     out = arena_sweep.run(8.0, seed=5, log=lambda s: None)
     assert out["summary"] == "all equal", out

@@ -240,12 +240,12 @@ def test_muzero_train_drop_in_other_loss_types(loss_type):
 
 
 def test_randomised_training_sweep_within_tolerance():
-    """Eight seconds of tools/train_sweep.py: random mlp_model / lstm_model shapes, unroll lengths, batch
+    """Eight seconds of tests/sweeps/train_sweep.py: random mlp_model / lstm_model shapes, unroll lengths, batch
     sizes, loss types, targets and weights — losses, gradient and priorities of mzs_train_grad within the
     fp32 tolerances of the oracle's train_grad (the long run: profiles/r2d_train_sweep.md)."""
     import os
     import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "sweeps"))
     import train_sweep
     out = train_sweep.run(8.0, seed=7, log=lambda s: None)
     assert out["summary"] == "all within tolerance", out
