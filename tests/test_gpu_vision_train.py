@@ -187,17 +187,20 @@ def random_vision_blob(rs, A, Sd, H, L):
     return np.concatenate(parts)
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(8))
 def test_vision_training_random_shapes_vs_oracle(seed):
     """Random head shapes, unroll lengths (K = 1: only forward-only dynamics), batch sizes (B = 1: batch statistics
-    of one sample), the four loss types, with and without importance weights, absorbing actions — one step against
-    the oracle, masks drawn here and injected into both."""
+    of one sample; B = 96 and 257: every reduction in several chunks, finished by the waves of the next kernel), the
+    four loss types, with and without importance weights, absorbing actions — one step against the oracle, masks
+    drawn here and injected into both."""
     from muzero_amd.engine import SearchEngine
     from muzero_amd.train import LOSS_TYPES, Trainer
     rs = np.random.RandomState(1000 + seed)
     A, Sd, H, L = int(rs.randint(2, 7)), int(rs.randint(3, 32)), int(rs.choice([8, 12, 33, 64])), int(rs.randint(1, 3))
     K, B = (1, 5) if seed == 0 else (int(rs.randint(2, 5)), 1 if seed == 1 else int(rs.randint(2, 11)))
-    loss_type = ["general", "general", "game_mmc", "game", "general_kkc", "general"][seed]
+    if seed >= 6:
+        K, B = 2, (96, 257)[seed - 6]
+    loss_type = ["general", "general", "game_mmc", "game", "general_kkc", "general", "general", "game_mmc"][seed]
     blob = random_vision_blob(rs, A, Sd, H, L)
     obs = rs.uniform(0.0, 1.0, size=(B, 3, 98, 98)).astype(np.float32)
     actions = np.zeros((K, B, A), np.float32)
