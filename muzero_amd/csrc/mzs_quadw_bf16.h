@@ -266,5 +266,262 @@ __device__ __forceinline__ void lstm_representation_quad_b(const Model& m, const
     wave_sync();
 }
 
+/* ==================================================================================================
+ * contract "dot_bf16x3" (MZS_PRECISION_BF16X3) on the weight stream: a chunk is a hi image followed by a lo
+ * image (2 x 8 KB = the fp32 chunk's 16 KB and its 64 registers, k_build_stream_x splits the fp32 store),
+ * the layer's input row is split when it is loaded, three matrix instructions per group of four k
+ * (hi hi -> the even / odd chains, hi lo -> s, lo hi -> t; mzs_quad_bf16.h quad_dense_x3_step), result
+ * (e + o) + (s + t).  48 matrix instructions per chunk and set of four games: the fp32 stream issues 64.
+ * ================================================================================================ */
+struct WideStreamX {
+    typedef const __attribute__((address_space(1))) u32x4_t* P4;
+    P4 img;
+    int n_img, next_img;
+    unsigned w[kBufs][64]; /* [0..31] hi halves, [32..63] lo halves, each as WideStreamB::w */
+    __device__ __forceinline__ void init(const float* images, int image0, int n_images, int lane) {
+        img = (P4)images + (size_t)image0 * 2 * kImageU4 + quad_neuron_of_lane(lane);
+        n_img = n_images;
+        next_img = 0;
+    }
+    template <int I, int j>
+    __device__ __forceinline__ void request() {
+        const P4 base = img + (size_t)next_img * 2 * kImageU4;
+        const u32x4_t vh = base[j * 64], vl = base[kImageU4 + j * 64];
+        unsigned(&wk)[64] = w[I % kBufs];
+        wk[4 * j] = vh[0], wk[4 * j + 1] = vh[1], wk[4 * j + 2] = vh[2], wk[4 * j + 3] = vh[3];
+        wk[32 + 4 * j] = vl[0], wk[32 + 4 * j + 1] = vl[1], wk[32 + 4 * j + 2] = vl[2], wk[32 + 4 * j + 3] = vl[3];
+    }
+    __device__ __forceinline__ void advance() { next_img = next_img + 1 == n_img ? 0 : next_img + 1; }
+    template <int I, int KV, int part>
+    __device__ __forceinline__ void load_part() {
+        if constexpr (16 * part < KV) request<I, 2 * part>();
+        if constexpr (16 * part + 8 < KV) request<I, 2 * part + 1>();
+        if constexpr (part == 3) advance();
+    }
+    template <int I, int KV = 64>
+    __device__ __forceinline__ void load() {
+        load_part<I, KV, 0>();
+        load_part<I, KV, 1>();
+        load_part<I, KV, 2>();
+        load_part<I, KV, 3>();
+    }
+    template <int I, int KV0>
+    __device__ __forceinline__ void start(int first) {
+        static_assert(kAhead == 1, "one chunk ahead");
+        next_img = first;
+        load<I, KV0>();
+    }
+};
+
+__device__ __forceinline__ SplitX wide_load_x3(const float* row, int grp) {
+    SplitX x;
+    quad_load_x3_f32(row, grp, x);
+    return x;
+}
+
+template <int K, int k0, int part, int NS, bool kFence = (NS > 1)>
+__device__ __forceinline__ void wide_quarter_x(const unsigned (&cur)[64], const SplitX (&x)[NS], f32x4 (&e)[NS],
+                                               f32x4 (&o)[NS], f32x4 (&s)[NS], f32x4 (&t)[NS]) {
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const int gi = 4 * part + gq;
+        if (k0 + 4 * gi < K) {
+            const s16x4 wh = as_s16x4(cur[2 * gi], cur[2 * gi + 1]);
+            const s16x4 wl = as_s16x4(cur[32 + 2 * gi], cur[32 + 2 * gi + 1]);
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const f32x4 a = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, x[i].h[gq], zero, 0, 0, 4 + part);
+                const f32x4 b = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, x[i].l[gq], zero, 0, 0, 4 + part);
+                const f32x4 c = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wl, x[i].h[gq], zero, 0, 0, 4 + part);
+                if (gi & 1) {
+                    if (k0 == 0 && gi == 1)
+                        o[i] = a;
+                    else
+                        o[i] = o[i] + a;
+                } else {
+                    e[i] = e[i] + a;
+                }
+                if (k0 == 0 && gi == 0) {
+                    s[i] = b;
+                    t[i] = c;
+                } else {
+                    s[i] = s[i] + b;
+                    t[i] = t[i] + c;
+                }
+            }
+            /* a group's 3 NS products are consumed before the next group's are issued: left to itself the
+             * scheduler hoists a quarter's 12 NS instructions ahead of their adds (48 NS result registers on top
+             * of the 128 of the stream: 528 spilled in the pair kernel) */
+            if constexpr (kFence) __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
+template <int K, int k0, int IN, int KV, int NS>
+__device__ __forceinline__ void wide_block_x(WideStreamX& st, const unsigned (&cur)[64], const SplitX (&x)[NS],
+                                             f32x4 (&e)[NS], f32x4 (&o)[NS], f32x4 (&s)[NS], f32x4 (&t)[NS]) {
+    st.template load_part<IN, KV, 0>();
+    __builtin_amdgcn_sched_barrier(0);
+    wide_quarter_x<K, k0, 0, NS>(cur, x, e, o, s, t);
+    __builtin_amdgcn_sched_barrier(0);
+    st.template load_part<IN, KV, 1>();
+    __builtin_amdgcn_sched_barrier(0);
+    wide_quarter_x<K, k0, 1, NS>(cur, x, e, o, s, t);
+    __builtin_amdgcn_sched_barrier(0);
+    st.template load_part<IN, KV, 2>();
+    __builtin_amdgcn_sched_barrier(0);
+    wide_quarter_x<K, k0, 2, NS>(cur, x, e, o, s, t);
+    __builtin_amdgcn_sched_barrier(0);
+    st.template load_part<IN, KV, 3>();
+    __builtin_amdgcn_sched_barrier(0);
+    wide_quarter_x<K, k0, 3, NS>(cur, x, e, o, s, t);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int K, int I, int KVL, int NS>
+__device__ __forceinline__ void wide_unit_sets_x(WideStreamX& st, const float* __restrict__ bias4,
+                                                 const float* const (&rows)[NS], int stride, const QuadLane& q,
+                                                 f32x4 (&out)[NS]) {
+    static_assert(K <= 128, "two chunks at most");
+    const float4 bv = *reinterpret_cast<const float4*>(bias4);
+    f32x4 e[NS], o[NS], s[NS], t[NS];
+    SplitX x[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        e[i] = f32x4{bv.x, bv.y, bv.z, bv.w};
+        o[i] = s[i] = t[i] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        x[i] = wide_load_x3(rows[i] + q.c * stride, q.grp);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    wide_block_x<K, 0, I + 1, (K > 64 ? 64 : KVL), NS>(st, st.w[I % kBufs], x, e, o, s, t);
+    if constexpr (K > 64) {
+        /* the second chunk's input halves replace the first's: 16 registers per set instead of 32 */
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x[i] = wide_load_x3(rows[i] + q.c * stride + 64, q.grp);
+        __builtin_amdgcn_sched_barrier(0);
+        wide_block_x<K, 64, I + 2, KVL, NS>(st, st.w[(I + 1) % kBufs], x, e, o, s, t);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NS; ++i) out[i] = (e[i] + o[i]) + (s[i] + t[i]);
+}
+
+template <int K, int I, int KVL = 64>
+__device__ __forceinline__ f32x4 wide_unit(WideStreamX& st, const float* __restrict__ bias4, const float* xrow,
+                                           const QuadLane& q) {
+    const float* const rows[1] = {xrow};
+    f32x4 out[1];
+    wide_unit_sets_x<K, I, KVL, 1>(st, bias4, rows, 0, q, out);
+    return out[0];
+}
+
+template <int K, int I, int KVL = 64>
+__device__ __forceinline__ void pair_unit(WideStreamX& st, const float* __restrict__ bias4, const float* x, int stride,
+                                          const QuadLane& q, f32x4 (&out)[2], unsigned long long* dg = nullptr) {
+    (void)dg;
+    const float* const rows[2] = {x, x + 4 * stride};
+    wide_unit_sets_x<K, I, KVL, 2>(st, bias4, rows, stride, q, out);
+}
+
+/* contract "dot_bf16x3" of a layer read from the fp32 store's W^T rows, split on the way (root only) */
+__device__ __forceinline__ f32x4 wide_dense_store_x(const float* __restrict__ w, const Layer ly, int K, int grp,
+                                                    const float* xrow, const QuadLane& q) {
+    const int npad = ly.n_pad;
+    const int n = quad_neuron_of_lane(q.lane);
+    const float4 bv = *reinterpret_cast<const float4*>(w + ly.b_off + 64 * grp + q.n0);
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    f32x4 e = f32x4{bv.x, bv.y, bv.z, bv.w}, o = zero, s = zero, t = zero;
+    const float* __restrict__ wt = w + ly.w_off + 64 * grp + n;
+    for (int k0 = 0; k0 < K; k0 += 64) {
+        const SplitX x = wide_load_x3(xrow + k0, q.grp);
+        const int ng = (min(K - k0, 64) + 3) / 4;
+        for (int gi = 0; gi < ng; ++gi) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = k0 + 4 * gi + u < K ? wt[(size_t)(k0 + 4 * gi + u) * npad] : 0.0f;
+            unsigned h0, l0, h1, l1;
+            split_pack(v[0], v[1], h0, l0);
+            split_pack(v[2], v[3], h1, l1);
+            const s16x4 wh = as_s16x4(h0, h1), wl = as_s16x4(l0, l1);
+            const s16x4 xh = x.h[gi & 3], xl = x.l[gi & 3];
+            f32x4 a, b, c;
+            switch (gi >> 2) {
+                case 0:
+                    a = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, xh, zero, 0, 0, 4);
+                    b = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, xl, zero, 0, 0, 4);
+                    c = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wl, xh, zero, 0, 0, 4);
+                    break;
+                case 1:
+                    a = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, xh, zero, 0, 0, 5);
+                    b = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, xl, zero, 0, 0, 5);
+                    c = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wl, xh, zero, 0, 0, 5);
+                    break;
+                case 2:
+                    a = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, xh, zero, 0, 0, 6);
+                    b = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, xl, zero, 0, 0, 6);
+                    c = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wl, xh, zero, 0, 0, 6);
+                    break;
+                default:
+                    a = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, xh, zero, 0, 0, 7);
+                    b = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, xl, zero, 0, 0, 7);
+                    c = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wl, xh, zero, 0, 0, 7);
+                    break;
+            }
+            const bool first = k0 == 0 && gi == 0;
+            if (gi & 1)
+                o = (k0 == 0 && gi == 1) ? a : o + a;
+            else
+                e = e + a;
+            s = first ? b : s + b;
+            t = first ? c : t + c;
+        }
+    }
+    return (e + o) + (s + t);
+}
+
+template <int SD, int H>
+__device__ __forceinline__ void wide_representation_x(const Model& m, const WideBufs& B, const QuadLane& q,
+                                                      float* hdst) {
+    constexpr int HP = (H + 63) / 64 * 64, NG = HP / 64;
+    float* xrow = B.xin + q.c * kWideXStride;
+    float* trow = B.trunk + q.c * kWideTStride;
+    f32x4 acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) acc[g] = wide_dense_store_x(m.w, m.r_in, m.obs_dim, g, xrow, q);
+    wave_sync();
+#pragma unroll
+    for (int g = 0; g < NG; ++g) store4(trow + 64 * g + q.n0, elu4<false>(acc[g]));
+    wave_sync();
+    for (int l = 0; l < m.L; ++l) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) acc[g] = wide_dense_store_x(m.w, m.r_mid, H, g, trow, q);
+        wave_sync();
+#pragma unroll
+        for (int g = 0; g < NG; ++g) store4(trow + 64 * g + q.n0, elu4<false>(acc[g]));
+        wave_sync();
+    }
+    const f32x4 a = wide_dense_store_x(m.w, m.r_out, H, 0, trow, q);
+    const f32x4 y = wide_scale_to_bound(a, wide_valid(q, SD));
+    wave_sync();
+    store4(xrow + q.n0, y);
+    store4(hdst + q.n0, y);
+    wave_sync();
+}
+
+template <int SD>
+__device__ __forceinline__ void lstm_representation_quad_x(const Model& m, const WideBufs& Bf, const QuadLane& q,
+                                                           float* hdst, int hid_stride) {
+    float* xrow = Bf.xin + q.c * kWideXStride;
+    f32x4 y = wide_dense_store_x(m.w, m.r_in, m.obs_dim, 0, xrow, q);
+    const WideValid vd = wide_valid(q, SD);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) y[r] = vd.v[r] ? y[r] : 0.0f;
+    wave_sync();
+    store4(xrow + q.n0, y);
+    if (q.n0 < hid_stride) store4(hdst + q.n0, y);
+    wave_sync();
+}
+
 }  // namespace mzs
 #endif

@@ -109,6 +109,7 @@ quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global, bool two
 /* "dot_bf16" instantiations of k_search_quadw2 / k_search_quadl (mzsearch_bf16.hip) for the shapes the fp32
  * pickers of mzsearch.hip accept */
 quad_kernel_t pick_wide_kernel_bf16(const mzs_dims& d);
+quad_kernel_t pick_wide_kernel_x3(const mzs_dims& d); /* mzsearch_x3w.hip */
 
 /* ------------------------------------------------------------------------------
  * Quad fused engine (mzs_quad.h): four games per wavefront, dense layers on

@@ -2,7 +2,8 @@
  * mzs_wide_kernels.h — the search kernels of the models whose weights ride the weight stream
  * (k_search_quadw2: wide MLP, mzs_quadw2.h; k_search_quadl: 'lstm_model', mzs_quadl.h) and the kernels that
  * build the stream's chunk images.  Templates, instantiated in mzsearch.hip (fp32: contract "dot") and in
- * mzsearch_bf16.hip (kB16: contract "dot_bf16" on the bf16 stream of mzs_quadw_bf16.h).
+ * mzsearch_bf16.hip (kB16 1: contract "dot_bf16" on the bf16 stream of mzs_quadw_bf16.h; 2: "dot_bf16x3" on its
+ * hi + lo stream).
  */
 #ifndef MZS_WIDE_KERNELS_H
 #define MZS_WIDE_KERNELS_H
@@ -29,7 +30,7 @@ __device__ __forceinline__ const float* tab_copy(float*& cursor, const float* sr
  * of every layer for the pair's eight.  One block = four waves = two pairs; every wave reaches
  * every block barrier.
  * ---------------------------------------------------------------------------- */
-template <int SD, int NA, int H, bool kB16 = false>
+template <int SD, int NA, int H, int kB16 = 0>
 __global__ void __launch_bounds__(256, 1) k_search_quadw2(const SearchParams p, const QuadLayout ql) {
     extern __shared__ __align__(16) unsigned char smem[];
     const QuadLane q = quad_lane();
@@ -63,7 +64,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw2(const SearchParams p, 
     B.trunk = L.trunk;
     B.xin = L.trunk + 4 * kWideTStride;
     const PairBufs P = pair_carve(reinterpret_cast<float*>(smem + ql.shared_bytes) - (2 - pair) * kPairFloats);
-    typename std::conditional<kB16, WideStreamB, WideStream>::type st;
+    typename std::conditional<kB16 == 2, WideStreamX, typename std::conditional<kB16 == 1, WideStreamB, WideStream>::type>::type st;
     const int n_half = p.n_img / 2;
     st.init(p.img, u * n_half, n_half, q.lane);
 
@@ -88,7 +89,9 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw2(const SearchParams p, 
     /* root: representation (each wave for its own games, from the store's rows) -> prediction (shared) */
     for (int k = q.b; k < kWideX; k += 16) xrow[k] = k < m.obs_dim ? p.obs[(size_t)g * m.obs_dim + k] : 0.0f;
     wave_sync();
-    if constexpr (kB16)
+    if constexpr (kB16 == 2)
+        wide_representation_x<SD, H>(m, B, q, hid_g);
+    else if constexpr (kB16 == 1)
         wide_representation_b<SD, H>(m, B, q, hid_g);
     else
         wide_representation<SD, H>(m, B, q, hid_g);
@@ -160,7 +163,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quadw2(const SearchParams p, 
  * k_search_quadl: four games per wave for the 'lstm_model' (mzs_quadl.h): the structure of
  * k_search_quadw with the LSTM heads.
  * ---------------------------------------------------------------------------- */
-template <int SD, int NA, int H, bool kB16 = false>
+template <int SD, int NA, int H, int kB16 = 0>
 __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, const QuadLayout ql) {
     extern __shared__ __align__(16) unsigned char smem[];
     const QuadLane q = quad_lane();
@@ -194,7 +197,7 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
     WideBufs B;
     B.trunk = L.trunk;
     B.xin = L.trunk + 4 * kWideTStride;
-    typename std::conditional<kB16, WideStreamB, WideStream>::type st;
+    typename std::conditional<kB16 == 2, WideStreamX, typename std::conditional<kB16 == 1, WideStreamB, WideStream>::type>::type st;
     st.init(p.img, 0, p.n_img, q.lane);
 
     const double* __restrict__ noise = p.noise ? p.noise + (size_t)g * p.noise_stride : nullptr;
@@ -209,7 +212,9 @@ __global__ void __launch_bounds__(256, 1) k_search_quadl(const SearchParams p, c
     f32x4 pr;
     for (int k = q.b; k < kWideX; k += 16) xrow[k] = k < m.obs_dim ? p.obs[(size_t)g * m.obs_dim + k] : 0.0f;
     wave_sync();
-    if constexpr (kB16)
+    if constexpr (kB16 == 2)
+        lstm_representation_quad_x<SD>(m, B, q, hid_g, hs);
+    else if constexpr (kB16 == 1)
         lstm_representation_quad_b<SD>(m, B, q, hid_g, hs);
     else
         lstm_representation_quad<SD>(m, B, q, hid_g, hs);
@@ -273,6 +278,22 @@ static __global__ void __launch_bounds__(256) k_build_stream_b(const float* __re
         const int k = i >> 6, n = i & 63;
         const float v = u.k0 + k < u.K ? w[u.w_off + (size_t)(u.k0 + k) * u.npad + n] : 0.0f;
         out[((k >> 3) * 64 + n) * 8 + (k & 7)] = (unsigned short)((unsigned)mzs_f2bits(v) >> 16);
+    }
+}
+
+/* ... and for the hi + lo stream (WideStreamX): per chunk a hi image then a lo image in the bf16 layout, split
+ * from the fp32 store (mzs_bf16_split: hi = round(v), lo = round(v - hi)) */
+static __global__ void __launch_bounds__(256) k_build_stream_x(const float* __restrict__ w, const StreamPlan plan,
+                                                               float* __restrict__ img) {
+    const StreamUnit u = plan.u[blockIdx.x];
+    unsigned short* out = reinterpret_cast<unsigned short*>(img) + (size_t)blockIdx.x * 2 * 64 * 64;
+    for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+        const int k = i >> 6, n = i & 63;
+        const float v = u.k0 + k < u.K ? w[u.w_off + (size_t)(u.k0 + k) * u.npad + n] : 0.0f;
+        unsigned hi, lo;
+        split_pack(v, 0.0f, hi, lo);
+        out[((k >> 3) * 64 + n) * 8 + (k & 7)] = (unsigned short)(hi & 0xffffu); /* split_pack: first value in the low half */
+        out[64 * 64 + ((k >> 3) * 64 + n) * 8 + (k & 7)] = (unsigned short)(lo & 0xffffu);
     }
 }
 

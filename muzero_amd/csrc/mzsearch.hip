@@ -965,18 +965,17 @@ quad_kernel_t pick_quad_kernel_occ2(const mzs_dims& d) {
 
 /* wide MLPs (mzs_quadw.h): the shape of experiments 127 / 128 */
 quad_kernel_t pick_quadw_kernel(const mzs_dims& d) {
-    if (d.model_kind != MZS_MODEL_MLP || d.obs_dim > 64 || d.precision == MZS_PRECISION_BF16X3) return nullptr;
+    if (d.model_kind != MZS_MODEL_MLP || d.obs_dim > 64) return nullptr;
     if (d.state_dim == 61 && d.hidden_dim == 128 && d.n_actions == 2)
-        return d.precision == MZS_PRECISION_BF16 ? mzs::pick_wide_kernel_bf16(d) : k_search_quadw2<61, 2, 128>;
+        return d.precision != MZS_PRECISION_F32 ? mzs::pick_wide_kernel_bf16(d) : k_search_quadw2<61, 2, 128>;
     return nullptr;
 }
 
 /* 'lstm_model' on the weight stream (mzs_quadl.h): one LSTM layer, the shape of the LSTM fixture */
 quad_kernel_t pick_quadl_kernel(const mzs_dims& d) {
-    if (d.model_kind != MZS_MODEL_LSTM || d.n_mid_layers != 1 || d.obs_dim > 64 || d.precision == MZS_PRECISION_BF16X3)
-        return nullptr;
+    if (d.model_kind != MZS_MODEL_LSTM || d.n_mid_layers != 1 || d.obs_dim > 64) return nullptr;
     if (d.state_dim == 31 && d.hidden_dim == 64 && d.n_actions == 2)
-        return d.precision == MZS_PRECISION_BF16 ? mzs::pick_wide_kernel_bf16(d) : k_search_quadl<31, 2, 64>;
+        return d.precision != MZS_PRECISION_F32 ? mzs::pick_wide_kernel_bf16(d) : k_search_quadl<31, 2, 64>;
     return nullptr;
 }
 
@@ -1130,7 +1129,8 @@ SearchPlan plan_search(const mzs_handle* h, int S, int n_games) {
             pl.ql = ql;
             pl.wpb = wpb;
             std::snprintf(pl.name, sizeof pl.name, "k_search_quad%s<%d,%d,%d%s>", lstm ? "l" : "w2", d.state_dim, A,
-                          d.hidden_dim, d.precision == MZS_PRECISION_BF16 ? ",bf16" : "");
+                          d.hidden_dim,
+                          d.precision == MZS_PRECISION_BF16 ? ",bf16" : (d.precision == MZS_PRECISION_BF16X3 ? ",bf16x3" : ""));
         }
     }
     return pl;
@@ -1536,7 +1536,10 @@ static int search_launch(mzs_handle* h, int32_t n_games, int32_t S, int32_t trai
     if (plan.kind == kPlanGeneric) return launch(k_search_fused<false>, p, n_games, p.lds, st);
     if (plan.kind == kPlanStream) {
         if (build_stream) {
-            if (h->cfg.dims.precision == MZS_PRECISION_BF16)
+            if (h->cfg.dims.precision == MZS_PRECISION_BF16X3) /* hi + lo images from the fp32 store */
+                hipLaunchKernelGGL(k_build_stream_x, dim3(h->stream_plan.n), dim3(256), 0, st, h->w_search_dev,
+                                   h->stream_plan, h->stream_dev);
+            else if (h->cfg.dims.precision == MZS_PRECISION_BF16)
                 hipLaunchKernelGGL(k_build_stream_b, dim3(h->stream_plan.n), dim3(256), 0, st, h->w_search_dev,
                                    h->stream_plan, h->stream_dev);
             else

@@ -47,10 +47,11 @@ quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global, bool two
 /* the weight-stream kernels on the bf16 stream (mzs_quadw_bf16.h): the wide MLP of experiments 127 / 128 and
  * the one-layer 'lstm_model' shape */
 quad_kernel_t pick_wide_kernel_bf16(const mzs_dims& d) {
+    if (d.precision == MZS_PRECISION_BF16X3) return pick_wide_kernel_x3(d); /* mzsearch_x3w.hip */
     if (d.model_kind == MZS_MODEL_MLP && d.state_dim == 61 && d.hidden_dim == 128 && d.n_actions == 2)
-        return k_search_quadw2<61, 2, 128, true>;
+        return k_search_quadw2<61, 2, 128, 1>;
     if (d.model_kind == MZS_MODEL_LSTM && d.state_dim == 31 && d.hidden_dim == 64 && d.n_actions == 2)
-        return k_search_quadl<31, 2, 64, true>;
+        return k_search_quadl<31, 2, 64, 1>;
     return nullptr;
 }
 

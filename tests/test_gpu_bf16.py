@@ -47,8 +47,8 @@ def test_bf16_inference_kernels_equal_oracle(tag, prec):
     eng.close()
 
 
-# tag -> kernel of the fast-bf16 weight-stream kernels (mzs_quadw_bf16.h): the wide MLP and the one-layer LSTM
-FAST_WIDE = {"tag127": "k_search_quadw2<61,2,128,bf16>", "lstmA": "k_search_quadl<31,2,64,bf16>"}
+# tag -> the weight-stream kernel (mzs_quadw_bf16.h: bf16 stream, hi + lo stream) of the wide MLP and the one-layer LSTM
+WIDE = {"tag127": "k_search_quadw2<61,2,128", "lstmA": "k_search_quadl<31,2,64"}
 
 BF16_SEARCHES = [("search_tag123_S50.npz", "tag123"), ("search_tag123_S11.npz", "tag123"),
                  ("search_tag123_S1.npz", "tag123"), ("search_tag123_S0.npz", "tag123"),
@@ -76,8 +76,8 @@ def test_bf16_search_equals_oracle(fname, tag, engine, prec):
     name = eng.search_kernel_name(S)
     if engine == "fused" and tag in ("tag123", "tag133", "synA4"):
         assert name.startswith("k_search_quad<") and name.endswith(SUFFIX[prec]), name
-    elif engine == "fused" and prec == 1 and tag in FAST_WIDE:
-        assert name == FAST_WIDE[tag], name
+    elif engine == "fused" and tag in WIDE:
+        assert name == WIDE[tag] + SUFFIX[prec], name
     else:
         assert name == "k_search_fused<false>", name
     eng.search(fx["obs"], dirichlet if train and S > 0 else None, noise if S > 0 else None, S, train)
@@ -146,10 +146,11 @@ def test_bf16_full_size_4096_games_vs_oracle(prec):
     eng.close()
 
 
+@pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("tag,G", [("tag127", 4096), ("tag127", 77), ("lstmA", 4096), ("lstmA", 5)])
-def test_bf16_stream_kernels_repeated_launches_vs_oracle(tag, G):
-    """The fast-bf16 weight-stream kernels (k_search_quadw2<..,bf16>: pairs of waves behind block barriers;
-    k_search_quadl<..,bf16>) at full size and on a ragged count: three launches in a row (race screen), each ==
+def test_bf16_stream_kernels_repeated_launches_vs_oracle(tag, G, prec):
+    """The bf16 weight-stream kernels (k_search_quadw2<..,bf16 | bf16x3>: pairs of waves behind block barriers;
+    k_search_quadl<..>) at full size and on a ragged count: three launches in a row (race screen), each ==
     the bf16 oracle on visit counts, root-value bits, consumed draws, leaves and value sums."""
     from muzero_amd import rng
     from oracle import mz_oracle as mzo
@@ -157,11 +158,11 @@ def test_bf16_stream_kernels_repeated_launches_vs_oracle(tag, G):
     S, A = 30, d.n_actions
     obs = np.random.RandomState(17).uniform(-0.5, 0.5, size=(G, d.obs_dim)).astype(np.float32)
     dirichlet, noise = rng.noise_streams(np.arange(G) + 9, A, S, 0.25, True)
-    ref = mzo.search(bf16_dims(d, 1), blob, S, 0.997, 0.25, rng.pbc_table(S), obs=obs, dirichlet=dirichlet, noise=noise,
+    ref = mzo.search(bf16_dims(d, prec), blob, S, 0.997, 0.25, rng.pbc_table(S), obs=obs, dirichlet=dirichlet, noise=noise,
                      train=True, n_threads=8, want=("visits", "root_value", "consumed", "node_vsum", "sim_leaf", "hidden"))
-    eng = make_engine(d, G, S)
+    eng = make_engine(d, G, S, prec=prec)
     eng.set_weights(blob)
-    assert eng.search_kernel_name(S) == FAST_WIDE[tag]
+    assert eng.search_kernel_name(S) == WIDE[tag] + SUFFIX[prec]
     for _ in range(3):
         eng.search(obs, dirichlet, noise, S, True)
         out, tree = eng.results_host(), eng.tree_host()
