@@ -141,12 +141,27 @@ __device__ __forceinline__ void wide_block_b(WideStreamB& st, const unsigned (&c
     __builtin_amdgcn_sched_barrier(0);
 }
 
+/* diagnostic build: the slots of mzs_quadw2.h PAIR_WAIT_T / PAIR_MFMA_T (0: waiting for the chunk's weights and
+ * the x rows, 5: the matrix block) */
+#ifdef MZS_DIAG
+#define X3_WAIT_T(n)                                            \
+    const unsigned long long xw0_##n = diag_stamp();            \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); \
+    const unsigned long long xw1_##n = diag_stamp();            \
+    if (dg) dg[0] += xw1_##n - xw0_##n
+#define X3_MFMA_T(n) \
+    if (dg) dg[5] += diag_stamp() - xw1_##n
+#else
+#define X3_WAIT_T(n)
+#define X3_MFMA_T(n)
+#endif
+
 /* one dense unit for NS sets of four games: rows[s] = the set's input rows in LDS (row of game c at
  * rows[s] + c * stride); out[s] = pre-activations of the lane's four neurons.  Stream phases as wide_unit. */
 template <int K, int I, int KVL, int NS>
 __device__ __forceinline__ void wide_unit_sets_b(WideStreamB& st, const float* __restrict__ bias4,
                                                  const float* const (&rows)[NS], int stride, const QuadLane& q,
-                                                 f32x4 (&out)[NS]) {
+                                                 f32x4 (&out)[NS], unsigned long long* dg = nullptr) {
     static_assert(K <= 128, "two chunks at most");
     const float4 bv = *reinterpret_cast<const float4*>(bias4);
     f32x4 e[NS], o[NS];
@@ -159,11 +174,20 @@ __device__ __forceinline__ void wide_unit_sets_b(WideStreamB& st, const float* _
         if constexpr (K > 64) y[s] = wide_load_xb(rows[s] + q.c * stride + 64, q.grp);
     }
     __builtin_amdgcn_sched_barrier(0);
+    X3_WAIT_T(0);
     wide_block_b<K, 0, I + 1, (K > 64 ? 64 : KVL), NS>(st, st.w[I % kBufs], x, e, o);
-    if constexpr (K > 64) wide_block_b<K, 64, I + 2, KVL, NS>(st, st.w[(I + 1) % kBufs], y, e, o);
+    X3_MFMA_T(0);
+    if constexpr (K > 64) {
+        X3_WAIT_T(1);
+        wide_block_b<K, 64, I + 2, KVL, NS>(st, st.w[(I + 1) % kBufs], y, e, o);
+        X3_MFMA_T(1);
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int s = 0; s < NS; ++s) out[s] = e[s] + o[s];
+    /* not pinned as wide_unit_sets_x pins its result: here the sunk adds (64 products at most) fit the register
+     * file, and the matrix instructions issuing back to back ahead of them measured faster (tag 127: 0.616 ms
+     * against 0.677 pinned) */
 }
 
 /* the overloads the shared model code of mzs_quadw.h / mzs_quadw2.h / mzs_quadl.h resolves to when it is
@@ -181,9 +205,8 @@ __device__ __forceinline__ f32x4 wide_unit(WideStreamB& st, const float* __restr
 template <int K, int I, int KVL = 64>
 __device__ __forceinline__ void pair_unit(WideStreamB& st, const float* __restrict__ bias4, const float* x, int stride,
                                           const QuadLane& q, f32x4 (&out)[2], unsigned long long* dg = nullptr) {
-    (void)dg;
     const float* const rows[2] = {x, x + 4 * stride};
-    wide_unit_sets_b<K, I, KVL, 2>(st, bias4, rows, stride, q, out);
+    wide_unit_sets_b<K, I, KVL, 2>(st, bias4, rows, stride, q, out, dg);
 }
 
 /* contract "dot_bf16" of a layer read from the ROUNDED store's W^T rows (root only: the representation net),
@@ -319,74 +342,97 @@ __device__ __forceinline__ SplitX wide_load_x3(const float* row, int grp) {
     return x;
 }
 
-template <int K, int k0, int part, int NS, bool kFence = (NS > 1)>
+/* the three products of one group of four k for NS sets of games, waiting for their adds */
+template <int NS>
+struct X3Pipe {
+    f32x4 a[NS], b[NS], c[NS];
+};
+/* the adds of group G of the layer (contract "dot_bf16x3": a -> the even / odd chain, b -> s, c -> t; o is
+ * assigned at group 1, s and t at group 0) */
+template <int NS>
+__device__ __forceinline__ void x3_retire(int G, const X3Pipe<NS>& p, f32x4 (&e)[NS], f32x4 (&o)[NS], f32x4 (&s)[NS],
+                                          f32x4 (&t)[NS]) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        if (G & 1)
+            o[i] = G == 1 ? p.a[i] : o[i] + p.a[i];
+        else
+            e[i] = e[i] + p.a[i];
+        s[i] = G == 0 ? p.b[i] : s[i] + p.b[i];
+        t[i] = G == 0 ? p.c[i] : t[i] + p.c[i];
+    }
+}
+
+/* groups 4 part .. 4 part + 3 of the chunk at k0.  Software pipeline: a group's 3 NS matrix instructions
+ * issue, then the 6 NS packed adds of the group BEFORE it (pipe), two behind each matrix instruction: no add
+ * waits on the matrix pipe.  The fence keeps one group's products live at a time (left to itself the scheduler
+ * hoists a quarter's 12 NS instructions ahead of their adds: 48 NS result registers on top of the 128 of the
+ * stream, 528 spilled in the pair kernel). */
+template <int K, int k0, int part, int NS, bool kPipe = true>
 __device__ __forceinline__ void wide_quarter_x(const unsigned (&cur)[64], const SplitX (&x)[NS], f32x4 (&e)[NS],
-                                               f32x4 (&o)[NS], f32x4 (&s)[NS], f32x4 (&t)[NS]) {
+                                               f32x4 (&o)[NS], f32x4 (&s)[NS], f32x4 (&t)[NS], X3Pipe<NS>& pipe) {
     const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
         const int gi = 4 * part + gq;
         if (k0 + 4 * gi < K) {
+            const int G = k0 / 4 + gi;
             const s16x4 wh = as_s16x4(cur[2 * gi], cur[2 * gi + 1]);
             const s16x4 wl = as_s16x4(cur[32 + 2 * gi], cur[32 + 2 * gi + 1]);
+            X3Pipe<NS> n;
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
-                const f32x4 a = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, x[i].h[gq], zero, 0, 0, 4 + part);
-                const f32x4 b = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, x[i].l[gq], zero, 0, 0, 4 + part);
-                const f32x4 c = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wl, x[i].h[gq], zero, 0, 0, 4 + part);
-                if (gi & 1) {
-                    if (k0 == 0 && gi == 1)
-                        o[i] = a;
-                    else
-                        o[i] = o[i] + a;
-                } else {
-                    e[i] = e[i] + a;
-                }
-                if (k0 == 0 && gi == 0) {
-                    s[i] = b;
-                    t[i] = c;
-                } else {
-                    s[i] = s[i] + b;
-                    t[i] = t[i] + c;
-                }
+                n.a[i] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, x[i].h[gq], zero, 0, 0, 4 + part);
+                n.b[i] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wh, x[i].l[gq], zero, 0, 0, 4 + part);
+                n.c[i] = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(wl, x[i].h[gq], zero, 0, 0, 4 + part);
             }
-            /* a group's 3 NS products are consumed before the next group's are issued: left to itself the
-             * scheduler hoists a quarter's 12 NS instructions ahead of their adds (48 NS result registers on top
-             * of the 128 of the stream: 528 spilled in the pair kernel) */
-            if constexpr (kFence) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (kPipe) {
+                if (G > 0) x3_retire<NS>(G - 1, pipe, e, o, s, t);
+                pipe = n;
+#pragma unroll
+                for (int i = 0; i < 3 * NS; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                }
+            } else {
+                x3_retire<NS>(G, n, e, o, s, t);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
 
 template <int K, int k0, int IN, int KV, int NS>
 __device__ __forceinline__ void wide_block_x(WideStreamX& st, const unsigned (&cur)[64], const SplitX (&x)[NS],
-                                             f32x4 (&e)[NS], f32x4 (&o)[NS], f32x4 (&s)[NS], f32x4 (&t)[NS]) {
+                                             f32x4 (&e)[NS], f32x4 (&o)[NS], f32x4 (&s)[NS], f32x4 (&t)[NS],
+                                             X3Pipe<NS>& pipe) {
     st.template load_part<IN, KV, 0>();
     __builtin_amdgcn_sched_barrier(0);
-    wide_quarter_x<K, k0, 0, NS>(cur, x, e, o, s, t);
+    wide_quarter_x<K, k0, 0, NS>(cur, x, e, o, s, t, pipe);
     __builtin_amdgcn_sched_barrier(0);
     st.template load_part<IN, KV, 1>();
     __builtin_amdgcn_sched_barrier(0);
-    wide_quarter_x<K, k0, 1, NS>(cur, x, e, o, s, t);
+    wide_quarter_x<K, k0, 1, NS>(cur, x, e, o, s, t, pipe);
     __builtin_amdgcn_sched_barrier(0);
     st.template load_part<IN, KV, 2>();
     __builtin_amdgcn_sched_barrier(0);
-    wide_quarter_x<K, k0, 2, NS>(cur, x, e, o, s, t);
+    wide_quarter_x<K, k0, 2, NS>(cur, x, e, o, s, t, pipe);
     __builtin_amdgcn_sched_barrier(0);
     st.template load_part<IN, KV, 3>();
     __builtin_amdgcn_sched_barrier(0);
-    wide_quarter_x<K, k0, 3, NS>(cur, x, e, o, s, t);
+    wide_quarter_x<K, k0, 3, NS>(cur, x, e, o, s, t, pipe);
     __builtin_amdgcn_sched_barrier(0);
 }
 
 template <int K, int I, int KVL, int NS>
 __device__ __forceinline__ void wide_unit_sets_x(WideStreamX& st, const float* __restrict__ bias4,
                                                  const float* const (&rows)[NS], int stride, const QuadLane& q,
-                                                 f32x4 (&out)[NS]) {
+                                                 f32x4 (&out)[NS], unsigned long long* dg = nullptr) {
     static_assert(K <= 128, "two chunks at most");
     const float4 bv = *reinterpret_cast<const float4*>(bias4);
     f32x4 e[NS], o[NS], s[NS], t[NS];
     SplitX x[NS];
+    X3Pipe<NS> pipe;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         e[i] = f32x4{bv.x, bv.y, bv.z, bv.w};
@@ -394,17 +440,29 @@ __device__ __forceinline__ void wide_unit_sets_x(WideStreamX& st, const float* _
         x[i] = wide_load_x3(rows[i] + q.c * stride, q.grp);
     }
     __builtin_amdgcn_sched_barrier(0);
-    wide_block_x<K, 0, I + 1, (K > 64 ? 64 : KVL), NS>(st, st.w[I % kBufs], x, e, o, s, t);
+    X3_WAIT_T(0);
+    wide_block_x<K, 0, I + 1, (K > 64 ? 64 : KVL), NS>(st, st.w[I % kBufs], x, e, o, s, t, pipe);
+    X3_MFMA_T(0);
     if constexpr (K > 64) {
         /* the second chunk's input halves replace the first's: 16 registers per set instead of 32 */
 #pragma unroll
         for (int i = 0; i < NS; ++i) x[i] = wide_load_x3(rows[i] + q.c * stride + 64, q.grp);
         __builtin_amdgcn_sched_barrier(0);
-        wide_block_x<K, 64, I + 2, KVL, NS>(st, st.w[(I + 1) % kBufs], x, e, o, s, t);
+        X3_WAIT_T(1);
+        wide_block_x<K, 64, I + 2, KVL, NS>(st, st.w[(I + 1) % kBufs], x, e, o, s, t, pipe);
+        X3_MFMA_T(1);
     }
+    x3_retire<NS>((K + 3) / 4 - 1, pipe, e, o, s, t); /* the last group's adds */
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int i = 0; i < NS; ++i) out[i] = (e[i] + o[i]) + (s[i] + t[i]);
+    for (int i = 0; i < NS; ++i) {
+        out[i] = (e[i] + o[i]) + (s[i] + t[i]);
+        /* the result is pinned HERE: where the model code consumes it under a branch (the pair kernel's two waves
+         * finish a layer differently), the optimiser otherwise sinks the whole add chains into that branch, behind
+         * the unit, and every matrix result waits for them in a register (768 of them: the accumulator file and
+         * scratch) */
+        asm volatile("" : "+v"(out[i]));
+    }
 }
 
 template <int K, int I, int KVL = 64>
@@ -419,9 +477,8 @@ __device__ __forceinline__ f32x4 wide_unit(WideStreamX& st, const float* __restr
 template <int K, int I, int KVL = 64>
 __device__ __forceinline__ void pair_unit(WideStreamX& st, const float* __restrict__ bias4, const float* x, int stride,
                                           const QuadLane& q, f32x4 (&out)[2], unsigned long long* dg = nullptr) {
-    (void)dg;
     const float* const rows[2] = {x, x + 4 * stride};
-    wide_unit_sets_x<K, I, KVL, 2>(st, bias4, rows, stride, q, out);
+    wide_unit_sets_x<K, I, KVL, 2>(st, bias4, rows, stride, q, out, dg);
 }
 
 /* contract "dot_bf16x3" of a layer read from the fp32 store's W^T rows, split on the way (root only) */

@@ -118,7 +118,17 @@ quad_kernel_t pick_wide_kernel_x3(const mzs_dims& d); /* mzsearch_x3w.hip */
  * ---------------------------------------------------------------------------- */
 #ifdef MZS_DIAG
 /* diagnostic build only: per-phase cycle sums (s_memtime), never read by product code */
-static __device__ unsigned long long g_diag[8];
+static __device__ unsigned long long g_diag[8]; /* one per translation unit */
+/* add this unit's counters to out8 and clear them */
+static inline bool diag_drain(unsigned long long* out8) {
+    unsigned long long v[8], z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(g_diag), sizeof v) != hipSuccess) return false;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z) != hipSuccess) return false;
+    for (int i = 0; i < 8; ++i) out8[i] += v[i];
+    return true;
+}
+bool diag_drain_bf16(unsigned long long* out8); /* mzsearch_bf16.hip */
+bool diag_drain_x3w(unsigned long long* out8);  /* mzsearch_x3w.hip */
 __device__ __forceinline__ unsigned long long diag_stamp() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);

@@ -1181,11 +1181,9 @@ const char* mzs_last_error(void) { return g_err.c_str(); }
 #ifdef MZS_DIAG
 /* diagnostic build only (not declared in mzsearch.h): read and clear the phase counters */
 int mzs_debug_counters(unsigned long long* out8) {
-    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (hipDeviceSynchronize() != hipSuccess) return MZS_E_HIP;
-    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_diag), sizeof z) != hipSuccess) return MZS_E_HIP;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_diag), z, sizeof z) != hipSuccess) return MZS_E_HIP;
-    return MZS_OK;
+    for (int i = 0; i < 8; ++i) out8[i] = 0;
+    return diag_drain(out8) && mzs::diag_drain_bf16(out8) && mzs::diag_drain_x3w(out8) ? MZS_OK : MZS_E_HIP;
 }
 #endif
 namespace {

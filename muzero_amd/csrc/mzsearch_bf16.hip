@@ -55,4 +55,8 @@ quad_kernel_t pick_wide_kernel_bf16(const mzs_dims& d) {
     return nullptr;
 }
 
+#ifdef MZS_DIAG
+bool diag_drain_bf16(unsigned long long* out8) { return diag_drain(out8); }
+#endif
+
 }  // namespace mzs

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Diagnostic (not a benchmark): per-phase share of wave cycles in k_search_quad / k_search_quadw,
 from a -DMZS_DIAG build of the library (s_memtime stamps).  Usage on the GPU box:
-MZS_LIB=$PWD/muzero_amd/libmzsearch_diag.so python profiles/diag_phases.py [weights tag]"""
+MZS_LIB=$PWD/muzero_amd/libmzsearch_diag.so python profiles/diag_phases.py [weights tag] [precision]"""
 import ctypes as C
 import os
 import sys
@@ -13,8 +13,9 @@ from muzero_amd import _lib, rng  # noqa: E402
 from muzero_amd.engine import SearchEngine  # noqa: E402
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "tag123"
+prec = int(sys.argv[2]) if len(sys.argv) > 2 else 0   # 0 fp32, 1 fast bf16, 2 bf16x3
 w = np.load(f"tests/golden/weights_{tag}.npz")
-dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (int(w["kind"]) if "kind" in w.files else 0,)
+dims = tuple(int(w[k]) for k in ("obs_dim", "A", "S_dim", "H", "L")) + (int(w["kind"]) if "kind" in w.files else 0, prec)
 G, S = 4096, 50
 obs = np.random.RandomState(1000).uniform(-0.05, 0.05, size=(G, dims[0])).astype(np.float32)
 dirichlet, noise = rng.noise_streams(np.arange(G), 2, S, 0.25, True)
