@@ -10,8 +10,8 @@
 
 namespace mzs {
 
-/* bf16 (contract "dot_bf16", kPrec 1; "dot_bf16x3", kPrec 2): the benchmark shape and its A = 4 sibling, with
- * or without tied mid layers */
+/* bf16 (contract "dot_bf16", kPrec 1; "dot_bf16x3", kPrec 2): every shape the fp32 kernel is instantiated for
+ * (mzsearch.hip pick_quad_kernel_t), with or without tied mid layers */
 template <bool kHidG, int kPrec>
 static quad_kernel_t pick_quad_kernel_b16_t(const mzs_dims& d) {
     if (d.obs_dim > 64 || d.model_kind != MZS_MODEL_MLP) return nullptr;
@@ -19,10 +19,13 @@ static quad_kernel_t pick_quad_kernel_b16_t(const mzs_dims& d) {
     if (d.state_dim == 31 && d.hidden_dim == 64) {
         switch (d.n_actions) {
             case 2: return mid ? k_search_quad<31, 2, 64, false, true, kHidG, kPrec> : k_search_quad<31, 2, 64, false, false, kHidG, kPrec>;
+            case 3: return mid ? k_search_quad<31, 3, 64, false, true, kHidG, kPrec> : k_search_quad<31, 3, 64, false, false, kHidG, kPrec>;
             case 4: return mid ? k_search_quad<31, 4, 64, false, true, kHidG, kPrec> : k_search_quad<31, 4, 64, false, false, kHidG, kPrec>;
             default: return nullptr;
         }
     }
+    if (d.state_dim == 11 && d.n_actions == 2 && d.hidden_dim == 16)
+        return mid ? k_search_quad<11, 2, 16, false, true, kHidG, kPrec> : k_search_quad<11, 2, 16, false, false, kHidG, kPrec>;
     return nullptr;
 }
 /* the same kernels compiled for two wavefronts per SIMD (hidden states in the global array) */

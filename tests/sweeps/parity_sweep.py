@@ -26,11 +26,11 @@ SHAPES = [
     # seventh entry 1: bf16 model half (weights and activations rounded to bf16, fp32 accumulation; the
     # oracle restates the same contract)
     (4, 2, 31, 64, 0, 0, 1), (8, 4, 31, 64, 0, 0, 1), (4, 2, 31, 64, 2, 0, 1), (8, 4, 31, 64, 1, 0, 1),
-    (5, 7, 19, 24, 1, 0, 1),
+    (5, 7, 19, 24, 1, 0, 1), (6, 3, 31, 64, 0, 0, 1), (4, 2, 11, 16, 2, 0, 1),
     (4, 2, 61, 128, 1, 0, 1), (4, 2, 31, 64, 1, 1, 1),                # bf16 on the weight-stream kernels (wide MLP, LSTM)
     # seventh entry 2: bf16x3 (hi + lo bfloat16 pairs, three products: what type_format=torch.bfloat16 selects)
     (4, 2, 31, 64, 0, 0, 2), (8, 4, 31, 64, 0, 0, 2), (4, 2, 31, 64, 2, 0, 2), (4, 2, 11, 16, 0, 0, 2),
-    (4, 2, 61, 128, 1, 0, 2), (4, 2, 31, 64, 1, 1, 2), (5, 7, 19, 24, 1, 0, 2),
+    (4, 2, 61, 128, 1, 0, 2), (4, 2, 31, 64, 1, 1, 2), (5, 7, 19, 24, 1, 0, 2), (6, 3, 31, 64, 1, 0, 2),
     # vision_model (kind 2: obs_dim = the image side): two launches per search (roots, simulations); small game
     # counts, the oracle's ResNet runs on the host
     (98, 2, 31, 64, 1, 2), (98, 4, 21, 32, 2, 2), (98, 3, 17, 70, 1, 2),

@@ -63,7 +63,7 @@ BF16_SEARCHES = [("search_tag123_S50.npz", "tag123"), ("search_tag123_S11.npz", 
 @pytest.mark.parametrize("fname,tag", BF16_SEARCHES)
 def test_bf16_search_equals_oracle(fname, tag, engine, prec):
     """Whole searches on the fixtures' inputs: the MFMA kernel (tag123: L = 0; tag133: tied mid
-    layers; synA4: four actions) and the any-shape kernel (everything else, and every shape under
+    layers; synA4: four actions), the weight-stream kernels (tag127, lstmA) and the any-shape kernel (synA3, and every shape under
     engine="generic") == bf16 oracle on every output bit, hidden states included."""
     from oracle import mz_oracle as mzo
     fx = load_golden(fname)
@@ -90,7 +90,8 @@ def test_bf16_search_equals_oracle(fname, tag, engine, prec):
 
 
 @pytest.mark.parametrize("shape", [(8, 4, 31, 64, 0), (4, 2, 31, 64, 0), (4, 2, 31, 64, 4), (8, 4, 31, 64, 1),
-                                   (64, 2, 31, 64, 0), (1, 2, 31, 64, 2)])
+                                   (64, 2, 31, 64, 0), (1, 2, 31, 64, 2), (6, 3, 31, 64, 0), (6, 3, 31, 64, 2),
+                                   (4, 2, 11, 16, 0), (3, 2, 11, 16, 3)])
 @pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("G,S", [(37, 50), (5, 7), (1, 50), (11, 120)])
 def test_bf16_quad_shapes_vs_oracle(shape, G, S, prec):
