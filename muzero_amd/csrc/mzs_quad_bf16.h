@@ -112,6 +112,22 @@ __device__ __forceinline__ void quad_load_xb(const unsigned short* row, int g, s
     x[3] = as_s16x4(v1.z, v1.w);
 }
 
+/* a + b as four v_add_f32 (each result passes through an empty asm, so the compiler cannot re-pack the adds into
+ * v_pk_add_f32; the adds themselves are the compiler's, matrix-result hazards included).  For the bf16x3 chains,
+ * three adds per matrix instruction: beside matrix instructions a packed fp32 add costs more than two plain ones
+ * (measured on one box: k_search_quad bf16x3 -6 %, k_search_quadw2 -9 %, k_search_quadl -4 %).  The fast contract's
+ * single chain measured the other way (tag 123 +3 %, tag 127 +14 %) and keeps the packed adds. */
+__device__ __forceinline__ f32x4 add4s(const f32x4 a, const f32x4 b) {
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float ri = a[i] + b[i];
+        asm("" : "+v"(ri));
+        r[i] = ri;
+    }
+    return r;
+}
+
 /* contract "dot_bf16" for the four games: NG independent MFMAs with a zero accumulator, even
  * groups added to the bias chain, odd groups to the chain that starts at group 1 */
 template <int I>
@@ -373,16 +389,16 @@ __device__ __forceinline__ void quad_dense_x3_step(const SplitRows<NG>& w, const
             if constexpr (I == 1)
                 o = a;
             else
-                o = o + a;
+                o = add4s(o, a);
         } else {
-            e = e + a;
+            e = add4s(e, a);
         }
         if constexpr (I == 0) {
             s = b;
             t = c;
         } else {
-            s = s + b;
-            t = t + c;
+            s = add4s(s, b);
+            t = add4s(t, c);
         }
         quad_dense_x3_step<NG, I + 1>(w, x, e, o, s, t);
     }

@@ -355,16 +355,16 @@ __device__ __forceinline__ void x3_retire(int G, const X3Pipe<NS>& p, f32x4 (&e)
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         if (G & 1)
-            o[i] = G == 1 ? p.a[i] : o[i] + p.a[i];
+            o[i] = G == 1 ? p.a[i] : add4s(o[i], p.a[i]);
         else
-            e[i] = e[i] + p.a[i];
-        s[i] = G == 0 ? p.b[i] : s[i] + p.b[i];
-        t[i] = G == 0 ? p.c[i] : t[i] + p.c[i];
+            e[i] = add4s(e[i], p.a[i]);
+        s[i] = G == 0 ? p.b[i] : add4s(s[i], p.b[i]);
+        t[i] = G == 0 ? p.c[i] : add4s(t[i], p.c[i]);
     }
 }
 
 /* groups 4 part .. 4 part + 3 of the chunk at k0.  Software pipeline: a group's 3 NS matrix instructions
- * issue, then the 6 NS packed adds of the group BEFORE it (pipe), two behind each matrix instruction: no add
+ * issue, then the 12 NS adds of the group BEFORE it (pipe: v_add_f32, add4s), four behind each matrix instruction: no add
  * waits on the matrix pipe.  The fence keeps one group's products live at a time (left to itself the scheduler
  * hoists a quarter's 12 NS instructions ahead of their adds: 48 NS result registers on top of the 128 of the
  * stream, 528 spilled in the pair kernel). */
@@ -392,7 +392,7 @@ __device__ __forceinline__ void wide_quarter_x(const unsigned (&cur)[64], const 
 #pragma unroll
                 for (int i = 0; i < 3 * NS; ++i) {
                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
                 }
             } else {
                 x3_retire<NS>(G, n, e, o, s, t);

@@ -68,6 +68,13 @@ class SearchEngine:
         self.stream_prefix = 0          # search_streams: draws written before the search (0: library default)
         self.num_simulations = 0
         self.has_weights = False
+        if self.precision != _lib.PRECISION_F32 and int(engine) == _lib.ENGINE_FUSED:
+            name = self.search_kernel_name()
+            if name.startswith("k_search_fused"):
+                import warnings
+                warnings.warn(f"bf16 search of shape {self.dims[:6]} runs on {name}: no matrix-core kernel is "
+                              "instantiated for it and the software bf16 dot product costs 5-100 x the fp32 "
+                              "kernel (DESIGN.md section 4); fp32 is the fast mode for this shape", stacklevel=2)
 
     def close(self):
         if getattr(self, "h", None):
