@@ -34,11 +34,15 @@ def main():
     ap.add_argument("--temperature", default="static_one_temperature", help="self_play.py temperature_scheduler mode")
     ap.add_argument("--scheduler", default=None, help="lr scheduler: cosineannealinglr, steplr, ...")
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16x3"],
+                    help="search / inference precision (training stays fp32): bf16x3 = type_format=torch.bfloat16's default")
     a = ap.parse_args()
     torch.manual_seed(a.seed)
     np.random.seed(a.seed)
     mz = Muzero(observation_space_dimensions=4, action_space_dimensions=2, state_space_dimensions=31,
-                hidden_layer_dimensions=64, number_of_hidden_layer=0, k_hypothetical_steps=a.unroll)
+                hidden_layer_dimensions=64, number_of_hidden_layer=0, k_hypothetical_steps=a.unroll,
+                **({} if a.dtype == "f32" else dict(type_format=torch.bfloat16,
+                                                    bf16_mode="fast" if a.dtype == "bf16" else "x3")))
     eng = SearchEngine(mz.dims, max_games=a.slots, max_simulations=a.sims, discount=0.997)
     eng.set_weights(mz.weights_blob())
     tr = Trainer(eng, a.unroll, a.batch, "adam", a.lr, a.scheduler, a.iterations * a.train_steps)
