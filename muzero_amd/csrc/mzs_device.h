@@ -173,30 +173,74 @@ __device__ __forceinline__ float wave_tree_sum(float v) {
     return h.lo + h.hi;
 }
 
+/* ---- the bf16 contracts of the any-shape kernels, on the matrix core, ONE game per wavefront ----
+ * v_mfma_f32_4x4x4_16B_bf16 is sixteen independent 4 x 4 x 4 products: in block b, lane 4 b + i supplies row i
+ * of A and lane 4 b + j column j of B, and lane 4 b + j receives column j of D.  Every lane passes its own
+ * neuron's four weights as its A row and the SAME four inputs as its B column; then D[i][j] = the dot product of
+ * neuron 4 b + i whatever j, and a lane finds its own neuron's in element lane & 3 of its result.  Three quarters
+ * of the instruction are redundant — it still replaces ~40 VALU instructions of the software restatement
+ * (mzs_dot4_bf16: exact products, an exact sum, one rounding), which made these paths 5-100 x slower than fp32. */
+typedef short dev_s16x4 __attribute__((ext_vector_type(4)));
+typedef float dev_f32x4 __attribute__((ext_vector_type(4)));
+typedef float dev_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 dev_bf16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned dev_u32x2 __attribute__((ext_vector_type(2)));
+
+/* two floats -> packed bfloat16 pair, round to nearest even (v_cvt_pk_bf16_f32 = mzs_f2bf16 on each) */
+__device__ __forceinline__ unsigned dev_pack_bf16(float lo, float hi) {
+    const dev_f32x2 v = {lo, hi};
+    const dev_bf16x2 r = __builtin_convertvector(v, dev_bf16x2);
+    unsigned u;
+    __builtin_memcpy(&u, &r, 4);
+    return u;
+}
+__device__ __forceinline__ dev_s16x4 dev_s16(unsigned a, unsigned b) {
+    const dev_u32x2 v = {a, b};
+    dev_s16x4 r;
+    __builtin_memcpy(&r, &v, 8);
+    return r;
+}
+/* mzs_bf16_split on two floats: packed hi halves, packed lo halves */
+__device__ __forceinline__ void dev_split_pack(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = dev_pack_bf16(a, b);
+    const float ah = __uint_as_float(hi << 16), bh = __uint_as_float(hi & 0xffff0000u);
+    lo = dev_pack_bf16(a - ah, b - bh);
+}
+/* mzs_dot4_bf16 of this lane's four weights with the wave's four inputs (every lane must be active) */
+__device__ __forceinline__ float dev_dot4_mfma(const dev_s16x4 w, const dev_s16x4 x, int lane) {
+    const dev_f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    const dev_f32x4 d = __builtin_amdgcn_mfma_f32_4x4x4bf16_1k(w, x, zero, 0, 0, 0);
+    const int i = lane & 3;
+    const float lo = i & 1 ? d[1] : d[0], hi = i & 1 ? d[3] : d[2];
+    return i & 2 ? hi : lo;
+}
+
 /* y = act(bias + W x): lane j owns neuron j (and j+64, ...); x is broadcast from LDS.
  * extra_row >= 0 adds that row of W^T after the chain (the one-hot action column of
  * the dynamics input, neural_network_mlp_model.py:87 + muzero_model.py:502). */
 template <bool kElu>
 __device__ __forceinline__ void wave_dense_bf16(const float* __restrict__ w, const Layer ly, const float* x,
                                                 float* out, int extra_row, int lane) {
-    /* contract "dot_bf16" without the matrix core (the any-shape kernels): mzs_dot4_bf16 restates
-     * what one v_mfma_f32_4x4x4_16B_bf16 returns, so this and the MFMA kernels agree bit for bit.
-     * The store holds the weights already rounded to bfloat16 (as floats): their high halves. */
+    /* contract "dot_bf16" of the any-shape kernels.  The store holds the weights already rounded to bfloat16
+     * (as floats): their high halves. */
     const int ng = (ly.k + 3) / 4;
     for (int j0 = 0; j0 < ly.n_pad; j0 += kWave) {
         const int j = j0 + lane;
         const float* __restrict__ wt = w + ly.w_off + j;
         float e = w[ly.b_off + j], o = 0.0f;
         for (int g = 0; g < ng; ++g) {
-            unsigned short wb[4], xb[4];
+            unsigned wb[4];
+            float xv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int k = 4 * g + q;
                 const bool in = k < ly.k;
-                wb[q] = in ? (unsigned short)((unsigned)mzs_f2bits(wt[(size_t)k * ly.n_pad]) >> 16) : (unsigned short)0;
-                xb[q] = in ? mzs_f2bf16(x[k]) : (unsigned short)0;
+                wb[q] = in ? (unsigned)mzs_f2bits(wt[(size_t)k * ly.n_pad]) : 0u;
+                xv[q] = in ? x[k] : 0.0f;
             }
-            const float d = mzs_dot4_bf16(wb, xb);
+            const dev_s16x4 w4 = dev_s16((wb[0] >> 16) | (wb[1] & 0xffff0000u), (wb[2] >> 16) | (wb[3] & 0xffff0000u));
+            const dev_s16x4 x4 = dev_s16(dev_pack_bf16(xv[0], xv[1]), dev_pack_bf16(xv[2], xv[3]));
+            const float d = dev_dot4_mfma(w4, x4, lane);
             if (g & 1)
                 o = g == 1 ? d : o + d;
             else
@@ -210,8 +254,8 @@ __device__ __forceinline__ void wave_dense_bf16(const float* __restrict__ w, con
     wave_sync();
 }
 
-/* contract "dot_bf16x3" without the matrix core: weights (from the fp32 store) and inputs split into hi + lo
- * bfloat16 pairs, three mzs_dot4_bf16 per group, four chains (include/mzs_numeric.h) */
+/* contract "dot_bf16x3" of the any-shape kernels: weights (from the fp32 store) and inputs split into hi + lo
+ * bfloat16 pairs, three products per group, four chains (include/mzs_numeric.h) */
 template <bool kElu>
 __device__ __forceinline__ void wave_dense_bf16x3(const float* __restrict__ w, const Layer ly, const float* x,
                                                   float* out, int extra_row, int lane) {
@@ -221,15 +265,21 @@ __device__ __forceinline__ void wave_dense_bf16x3(const float* __restrict__ w, c
         const float* __restrict__ wt = w + ly.w_off + j;
         float e = w[ly.b_off + j], o = 0.0f, s = 0.0f, t = 0.0f;
         for (int g = 0; g < ng; ++g) {
-            unsigned short wh[4], wl[4], xh[4], xl[4];
+            float wv[4], xv[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int k = 4 * g + q;
                 const bool in = k < ly.k;
-                mzs_bf16_split(in ? wt[(size_t)k * ly.n_pad] : 0.0f, &wh[q], &wl[q]);
-                mzs_bf16_split(in ? x[k] : 0.0f, &xh[q], &xl[q]);
+                wv[q] = in ? wt[(size_t)k * ly.n_pad] : 0.0f;
+                xv[q] = in ? x[k] : 0.0f;
             }
-            const float a = mzs_dot4_bf16(wh, xh), b = mzs_dot4_bf16(wh, xl), c = mzs_dot4_bf16(wl, xh);
+            unsigned wh0, wl0, wh1, wl1, xh0, xl0, xh1, xl1;
+            dev_split_pack(wv[0], wv[1], wh0, wl0);
+            dev_split_pack(wv[2], wv[3], wh1, wl1);
+            dev_split_pack(xv[0], xv[1], xh0, xl0);
+            dev_split_pack(xv[2], xv[3], xh1, xl1);
+            const dev_s16x4 wh = dev_s16(wh0, wh1), wl = dev_s16(wl0, wl1), xh = dev_s16(xh0, xh1), xl = dev_s16(xl0, xl1);
+            const float a = dev_dot4_mfma(wh, xh, lane), b = dev_dot4_mfma(wh, xl, lane), c = dev_dot4_mfma(wl, xh, lane);
             if (g & 1)
                 o = g == 1 ? a : o + a;
             else

@@ -72,9 +72,9 @@ class SearchEngine:
             name = self.search_kernel_name()
             if name.startswith("k_search_fused"):
                 import warnings
-                warnings.warn(f"bf16 search of shape {self.dims[:6]} runs on {name}: no matrix-core kernel is "
-                              "instantiated for it and the software bf16 dot product costs 5-100 x the fp32 "
-                              "kernel (DESIGN.md section 4); fp32 is the fast mode for this shape", stacklevel=2)
+                warnings.warn(f"bf16 search of shape {self.dims[:6]} runs on {name}: no four-games-per-wave kernel "
+                              "is instantiated for it, and on the any-shape kernel bf16 costs about twice the fp32 "
+                              "search (DESIGN.md section 4); fp32 is the fast mode for this shape", stacklevel=2)
 
     def close(self):
         if getattr(self, "h", None):

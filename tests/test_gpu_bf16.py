@@ -1,6 +1,7 @@
 """GPU parity of the bf16 variants (Muzero(type_format=torch.bfloat16); include/mzs_numeric.h
-"dot_bf16x3" = precision 2, the default, and "dot_bf16" = precision 1, bf16_mode="fast"): the HIP kernels — v_mfma_f32_4x4x4_16B_bf16 in k_search_quad<..., bf16>, the software
-restatement of that instruction in the any-shape kernels — against the bf16 oracle, bit for bit,
+"dot_bf16x3" = precision 2, the default, and "dot_bf16" = precision 1, bf16_mode="fast"): the HIP kernels — v_mfma_f32_4x4x4_16B_bf16
+in k_search_quad<..., bf16>, in the weight-stream kernels and (one game per wave) in the any-shape kernels — against the bf16
+oracle (whose mzs_dot4_bf16 restates that instruction), bit for bit,
 through the C-ABI.  Accuracy against the reference (1e-2) is the oracle's: tests/test_bf16_oracle.py."""
 import numpy as np
 import pytest
@@ -27,7 +28,7 @@ def make_engine(d, G, S, gamma=0.997, frac=0.25, engine="fused", prec=1):
 @pytest.mark.parametrize("prec", PRECISIONS)
 @pytest.mark.parametrize("tag", MODEL_TAGS)
 def test_bf16_inference_kernels_equal_oracle(tag, prec):
-    """initial / recurrent / prediction inference (any-shape kernels: mzs_dot4_bf16 in software),
+    """initial / recurrent / prediction inference (any-shape kernels: the matrix instruction with one game per wave, mzs_device.h dev_dot4_mfma),
     MLP and LSTM models, both bf16 contracts."""
     from oracle import mz_oracle as mzo
     d, blob = fixture_weights(tag)
