@@ -110,6 +110,9 @@ quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global, bool two
  * pickers of mzsearch.hip accept */
 quad_kernel_t pick_wide_kernel_bf16(const mzs_dims& d);
 quad_kernel_t pick_wide_kernel_x3(const mzs_dims& d); /* mzsearch_x3w.hip */
+/* mzsearch_f32v.hip: the fp32 kernels that gain from matrix results in VGPRs */
+quad_kernel_t pick_quad_kernel_f32v(const mzs_dims& d, bool hid_global);
+quad_kernel_t pick_wide_kernel_f32v(const mzs_dims& d);
 
 /* ------------------------------------------------------------------------------
  * Quad fused engine (mzs_quad.h): four games per wavefront, dense layers on
@@ -129,6 +132,7 @@ static inline bool diag_drain(unsigned long long* out8) {
 }
 bool diag_drain_bf16(unsigned long long* out8); /* mzsearch_bf16.hip */
 bool diag_drain_x3w(unsigned long long* out8);  /* mzsearch_x3w.hip */
+bool diag_drain_f32v(unsigned long long* out8); /* mzsearch_f32v.hip */
 __device__ __forceinline__ unsigned long long diag_stamp() {
     unsigned long long t;
     __builtin_amdgcn_sched_barrier(0);

@@ -934,10 +934,13 @@ quad_kernel_t pick_quad_kernel_t(const mzs_dims& d) {
     if (d.obs_dim > 64 || d.model_kind != MZS_MODEL_MLP) return nullptr;
     const bool mid = d.n_mid_layers != 0; /* tied mid layers (any count): H more register-resident rows per net */
     if (d.state_dim == 31 && d.hidden_dim == 64) {
+        /* without mid layers: the instantiations of mzsearch_f32v.hip (matrix results in VGPRs: -1.6 % on the
+         * benchmark shape; the tied-mid kernels, whose weights fill the accumulator file, lose 10 % that way) */
+        if (!mid) return mzs::pick_quad_kernel_f32v(d, kHidG);
         switch (d.n_actions) {
-            case 2: return mid ? k_search_quad<31, 2, 64, false, true, kHidG> : k_search_quad<31, 2, 64, false, false, kHidG>;
-            case 3: return mid ? k_search_quad<31, 3, 64, false, true, kHidG> : k_search_quad<31, 3, 64, false, false, kHidG>;
-            case 4: return mid ? k_search_quad<31, 4, 64, false, true, kHidG> : k_search_quad<31, 4, 64, false, false, kHidG>;
+            case 2: return k_search_quad<31, 2, 64, false, true, kHidG>;
+            case 3: return k_search_quad<31, 3, 64, false, true, kHidG>;
+            case 4: return k_search_quad<31, 4, 64, false, true, kHidG>;
             default: return nullptr;
         }
     }
@@ -967,7 +970,7 @@ quad_kernel_t pick_quad_kernel_occ2(const mzs_dims& d) {
 quad_kernel_t pick_quadw_kernel(const mzs_dims& d) {
     if (d.model_kind != MZS_MODEL_MLP || d.obs_dim > 64) return nullptr;
     if (d.state_dim == 61 && d.hidden_dim == 128 && d.n_actions == 2)
-        return d.precision != MZS_PRECISION_F32 ? mzs::pick_wide_kernel_bf16(d) : k_search_quadw2<61, 2, 128>;
+        return d.precision != MZS_PRECISION_F32 ? mzs::pick_wide_kernel_bf16(d) : mzs::pick_wide_kernel_f32v(d);
     return nullptr;
 }
 
@@ -975,7 +978,7 @@ quad_kernel_t pick_quadw_kernel(const mzs_dims& d) {
 quad_kernel_t pick_quadl_kernel(const mzs_dims& d) {
     if (d.model_kind != MZS_MODEL_LSTM || d.n_mid_layers != 1 || d.obs_dim > 64) return nullptr;
     if (d.state_dim == 31 && d.hidden_dim == 64 && d.n_actions == 2)
-        return d.precision != MZS_PRECISION_F32 ? mzs::pick_wide_kernel_bf16(d) : k_search_quadl<31, 2, 64>;
+        return d.precision != MZS_PRECISION_F32 ? mzs::pick_wide_kernel_bf16(d) : mzs::pick_wide_kernel_f32v(d);
     return nullptr;
 }
 
@@ -1183,7 +1186,8 @@ const char* mzs_last_error(void) { return g_err.c_str(); }
 int mzs_debug_counters(unsigned long long* out8) {
     if (hipDeviceSynchronize() != hipSuccess) return MZS_E_HIP;
     for (int i = 0; i < 8; ++i) out8[i] = 0;
-    return diag_drain(out8) && mzs::diag_drain_bf16(out8) && mzs::diag_drain_x3w(out8) ? MZS_OK : MZS_E_HIP;
+    return diag_drain(out8) && mzs::diag_drain_bf16(out8) && mzs::diag_drain_x3w(out8) && mzs::diag_drain_f32v(out8) ? MZS_OK
+                                                                                                                  : MZS_E_HIP;
 }
 #endif
 namespace {

@@ -275,3 +275,20 @@ def test_bf16_muzero_drop_in(mode, prec):
             assert rel_err(root.value(), fx["root_value"][g]) < 1e-2
     p, v = mz.prediction_function_inference(torch.tensor(fx["root_hidden"][:1]))
     assert p.dtype == np.float32 and isinstance(v, np.float32)
+
+
+def test_bf16_on_any_shape_kernel_warns():
+    """A bf16 engine whose shape has no four-games-per-wave kernel says so (it runs at about twice the fp32 time);
+    a specialised shape, fp32 and the forced generic engine stay silent."""
+    import warnings
+    from oracle import mz_oracle as mzo
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        make_engine(mzo.dims(6, 3, 21, 32, 2), 8, 10, prec=2).close()
+    assert len(rec) == 1 and "k_search_fused" in str(rec[0].message)
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        make_engine(mzo.dims(4, 2, 31, 64, 0), 8, 10, prec=2).close()
+        make_engine(mzo.dims(6, 3, 21, 32, 2), 8, 10, prec=0).close()
+        make_engine(mzo.dims(6, 3, 21, 32, 2), 8, 10, engine="generic", prec=1).close()
+    assert not rec
