@@ -30,7 +30,8 @@ def main():
     ap.add_argument("--games-per-round", type=int, default=0, help="default 8 x --games")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--train-steps", type=int, default=50)
-    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16"), help="precision of the model half of the search")
+    ap.add_argument("--dtype", default="f32", choices=("f32", "bf16", "bf16x3"),
+                    help="precision of the model half of the search (bf16 = the fast contract, bf16x3 = hi + lo pairs)")
     ap.add_argument("--rolling", action="store_true",
                     help="queue the next round's games while the current one drains (SelfPlay(rolling=True))")
     ap.add_argument("--gpus", type=int, default=1, help="ranks (one per GPU); > 1 starts them itself")
@@ -53,7 +54,7 @@ def main():
     torch.cuda.set_device(local)
 
     G, S, T = a.games, a.sims, a.max_moves
-    dims = (4, 2, 31, 64, 0, 0, 1 if a.dtype == "bf16" else 0)
+    dims = (4, 2, 31, 64, 0, 0, {"f32": 0, "bf16": 1, "bf16x3": 2}[a.dtype])
     eng = SearchEngine(dims, max_games=G, max_simulations=S, discount=0.997, device=local)
     n = eng.weight_count()
     w0 = (np.random.RandomState(0).standard_normal(n) * 0.1).astype(np.float32)
