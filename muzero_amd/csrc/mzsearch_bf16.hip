@@ -39,7 +39,8 @@ static quad_kernel_t pick_quad_kernel_b16_occ2(const mzs_dims& d) {
     return nullptr;
 }
 quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global, bool two_per_simd) {
-    if (d.precision == MZS_PRECISION_BF16X3) { /* hi + lo weight pairs: the fp32 kernel's register count, one wave per SIMD */
+    if (d.precision == MZS_PRECISION_BF16X3) { /* hi + lo weight pairs: the fp32 kernel's register count, one wave per SIMD
+                                                * (built for two: 392 registers spilled, 8192 games 0.584 ms against 0.489) */
         if (two_per_simd) return nullptr;
         return hid_global ? pick_quad_kernel_b16_t<true, 2>(d) : pick_quad_kernel_b16_t<false, 2>(d);
     }
