@@ -2,7 +2,9 @@
 """Op-class sequence of a kernel in the saved ISA (make -C muzero_amd/csrc asm): where the waits,
 barriers, LDS-DMA requests and matrix blocks of the ring kernels fall.  usage: isa_steps.py <mangled-substring> [start] [len]"""
 import re, sys
-s = open('build/mzsearch-hip-amdgcn-amd-amdhsa-gfx950.s').read()
+import glob
+# every kernel unit of the library (mzsearch, mzsearch_f32v, mzsearch_bf16, mzsearch_x3w)
+s = "\n".join(open(f).read() for f in sorted(glob.glob('build/mzsearch*-hip-amdgcn-amd-amdhsa-gfx950.s')))
 pat = sys.argv[1]
 m = [m for m in re.finditer(r'^(\S*' + re.escape(pat) + r'\S*):\s*(?:;.*)?\n', s, re.M)][0]
 body = s[m.end():s.index('s_endpgm', m.end())].split('\n')
