@@ -1,12 +1,12 @@
 /*
  * mzsearch_bf16.hip — the bf16 instantiations of k_search_quad (mzs_search_kernels.h,
  * mzs_quad_bf16.h), a translation unit of their own because they want MFMA results in VGPRs
- * (-mllvm -amdgpu-mfma-vgpr-form, see muzero_amd/csrc/Makefile); part of libmzsearch.so.
+ * (-mllvm -amdgpu-mfma-vgpr-form, see muzero_amd/csrc/Makefile); part of libmzsearch.so.  The bf16 weight-stream
+ * kernels live in mzsearch_x3w.hip.
  */
 #include <hip/hip_runtime.h>
 
 #include "mzs_search_kernels.h"
-#include "mzs_wide_kernels.h"
 
 namespace mzs {
 
@@ -46,17 +46,6 @@ quad_kernel_t pick_quad_kernel_bf16(const mzs_dims& d, bool hid_global, bool two
     }
     if (two_per_simd) return hid_global ? pick_quad_kernel_b16_occ2(d) : nullptr;
     return hid_global ? pick_quad_kernel_b16_t<true, 1>(d) : pick_quad_kernel_b16_t<false, 1>(d);
-}
-
-/* the weight-stream kernels on the bf16 stream (mzs_quadw_bf16.h): the wide MLP of experiments 127 / 128 and
- * the one-layer 'lstm_model' shape */
-quad_kernel_t pick_wide_kernel_bf16(const mzs_dims& d) {
-    if (d.precision == MZS_PRECISION_BF16X3) return pick_wide_kernel_x3(d); /* mzsearch_x3w.hip */
-    if (d.model_kind == MZS_MODEL_MLP && d.state_dim == 61 && d.hidden_dim == 128 && d.n_actions == 2)
-        return k_search_quadw2<61, 2, 128, 1>;
-    if (d.model_kind == MZS_MODEL_LSTM && d.state_dim == 31 && d.hidden_dim == 64 && d.n_actions == 2)
-        return k_search_quadl<31, 2, 64, 1>;
-    return nullptr;
 }
 
 #ifdef MZS_DIAG
