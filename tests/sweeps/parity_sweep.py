@@ -28,6 +28,7 @@ SHAPES = [
     (4, 2, 31, 64, 0, 0, 1), (8, 4, 31, 64, 0, 0, 1), (4, 2, 31, 64, 2, 0, 1), (8, 4, 31, 64, 1, 0, 1),
     (5, 7, 19, 24, 1, 0, 1), (6, 3, 31, 64, 0, 0, 1), (4, 2, 11, 16, 2, 0, 1),
     (4, 2, 61, 128, 1, 0, 1), (4, 2, 31, 64, 1, 1, 1),                # bf16 on the weight-stream kernels (wide MLP, LSTM)
+    (4, 2, 31, 64, 2, 1, 1), (4, 2, 31, 64, 3, 1, 2), (3, 2, 128, 40, 0, 0, 2),   # bf16 on the any-shape kernel: deeper LSTMs, wide state
     # seventh entry 2: bf16x3 (hi + lo bfloat16 pairs, three products: what type_format=torch.bfloat16 selects)
     (4, 2, 31, 64, 0, 0, 2), (8, 4, 31, 64, 0, 0, 2), (4, 2, 31, 64, 2, 0, 2), (4, 2, 11, 16, 0, 0, 2),
     (4, 2, 61, 128, 1, 0, 2), (4, 2, 31, 64, 1, 1, 2), (5, 7, 19, 24, 1, 0, 2), (6, 3, 31, 64, 1, 0, 2),

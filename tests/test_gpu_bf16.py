@@ -56,7 +56,7 @@ BF16_SEARCHES = [("search_tag123_S50.npz", "tag123"), ("search_tag123_S11.npz", 
                  ("search_tag123_S50_notrain.npz", "tag123"), ("search_tag123_S50_wide.npz", "tag123"),
                  ("search_tag133_S50.npz", "tag133"), ("search_synA4_S50.npz", "synA4"),
                  ("search_tag127_S50.npz", "tag127"), ("search_synA3_S30.npz", "synA3"),
-                 ("search_lstmA_S50.npz", "lstmA")]
+                 ("search_lstmA_S50.npz", "lstmA"), ("search_lstmB_S30.npz", "lstmB")]
 
 
 @pytest.mark.parametrize("prec", PRECISIONS)
